@@ -1,0 +1,328 @@
+/* scenario_driver.c -- replay a chunk-write scenario through the pgsd C ABI.
+ *
+ * Test infrastructure.  ONE source, TWO builds:
+ *
+ *   -DPGSD_DRIVER_REF   links the reference's own pgsd.c (compiled in place from
+ *                       /root/reference by oracle/Makefile, output in oracle/_ref/)
+ *                       and runs under MPICH `mpiexec -n P`.  This produces the golden
+ *                       .gsd files committed under tests/golden/.
+ *   (default)           links libpgsd_amd.so (this repo's product) and takes
+ *                       rank/size from the shared-memory communicator
+ *                       (PGSD_RANK / PGSD_NRANKS / PGSD_SHM_NAME), one process per rank.
+ *
+ * Both builds make exactly the same pgsd_* calls (the drop-in boundary of
+ * /root/reference/pgsd/pgsd/pgsd.h:362-735), so `cmp` of the two output files is the
+ * parity check of the host file layer.
+ *
+ * The call sequence per chunk follows the two in-tree callers of the reference:
+ *   - per-particle arrays (all=1): benchmark-write.cc:91-102 and fl.pyx:594-652
+ *       N=N_local, N_global=sum, offset=M*sum_{j<rank}, global_size=N_global*M
+ *   - replicated small chunks (all=0): fl.pyx:594-652 with offset=None
+ *       N_global=N, offset=0, global_size=N*M
+ *
+ * Script grammar (one command per line, '#' starts a comment):
+ *   create <application> <schema> <major> <minor> <rw|append> <excl 0|1>
+ *   open <rw|ro|append>
+ *   seed <u64>
+ *   chunk <name> <u8|u16|u32|u64|i8|i16|i32|i64|f32|f64> <M> <all 0|1> <dist>
+ *         dist = even:<Nglobal> | same:<N> | list:<n0>,<n1>,...   (list is cycled over ranks)
+ *   rawchunk <name> <type> <N> <M> <N_global> <M_global> <offset> <global_size> <all>
+ *   end_frame | flush | close | dump
+ *   maxbuf <bytes> | idxbuf <entries>
+ *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
+ *   names <prefix>                 (prints matching chunk names on rank 0)
+ */
+#include "pgsd.h"
+
+#include <inttypes.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef PGSD_DRIVER_REF
+#include <mpi.h>
+#endif
+
+static int g_rank = 0, g_size = 1;
+
+static uint64_t mix64(uint64_t seed, uint64_t gid, uint32_t c, uint32_t M)
+    {
+    uint64_t u = (gid * (uint64_t)M + (uint64_t)c) * 0x9E3779B97F4A7C15ull
+                 + seed * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+    u ^= u >> 29;
+    u *= 0xBF58476D1CE4E5B9ull;
+    u ^= u >> 32;
+    return u;
+    }
+
+static int parse_type(const char* s, size_t* sz)
+    {
+    static const char* names[] = {"u8", "u16", "u32", "u64", "i8", "i16", "i32", "i64", "f32", "f64"};
+    static const size_t sizes[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8};
+    for (int i = 0; i < 10; i++)
+        {
+        if (strcmp(s, names[i]) == 0)
+            {
+            *sz = sizes[i];
+            return i + 1; /* pgsd_type values 1..10, pgsd.h:38-69 */
+            }
+        }
+    fprintf(stderr, "bad type %s\n", s);
+    exit(2);
+    }
+
+/* fill rows [gid0, gid0+N) x M of the given pgsd type */
+static void* gen_data(int type, uint64_t seed, uint64_t gid0, uint64_t N, uint32_t M, size_t sz)
+    {
+    if (N == 0)
+        return NULL;
+    char* buf = (char*)malloc(N * M * sz);
+    for (uint64_t i = 0; i < N; i++)
+        for (uint32_t c = 0; c < M; c++)
+            {
+            uint64_t u = mix64(seed, gid0 + i, c, M);
+            char* p = buf + (i * M + c) * sz;
+            double d = ((double)(u % 2000001ull) - 1000000.0) * 0.001;
+            switch (type)
+                {
+                case 1: { uint8_t v = (uint8_t)u; memcpy(p, &v, 1); break; }
+                case 2: { uint16_t v = (uint16_t)u; memcpy(p, &v, 2); break; }
+                case 3: { uint32_t v = (uint32_t)u; memcpy(p, &v, 4); break; }
+                case 4: { uint64_t v = u; memcpy(p, &v, 8); break; }
+                case 5: { uint8_t v = (uint8_t)u; memcpy(p, &v, 1); break; }
+                case 6: { uint16_t v = (uint16_t)u; memcpy(p, &v, 2); break; }
+                case 7: { uint32_t v = (uint32_t)u; memcpy(p, &v, 4); break; }
+                case 8: { uint64_t v = u; memcpy(p, &v, 8); break; }
+                case 9: { float v = (float)d; memcpy(p, &v, 4); break; }
+                case 10: { memcpy(p, &d, 8); break; }
+                }
+            }
+    return buf;
+    }
+
+static void dist_counts(const char* dist, uint64_t* counts)
+    {
+    if (strncmp(dist, "even:", 5) == 0)
+        {
+        /* benchmark-write.cc:33-37 */
+        uint64_t n = strtoull(dist + 5, NULL, 10);
+        for (int r = 0; r < g_size; r++)
+            counts[r] = n / g_size + (((uint64_t)r < n % g_size) ? 1 : 0);
+        }
+    else if (strncmp(dist, "same:", 5) == 0)
+        {
+        uint64_t n = strtoull(dist + 5, NULL, 10);
+        for (int r = 0; r < g_size; r++)
+            counts[r] = n;
+        }
+    else if (strncmp(dist, "list:", 5) == 0)
+        {
+        uint64_t vals[64];
+        int nv = 0;
+        char tmp[512];
+        strncpy(tmp, dist + 5, sizeof(tmp) - 1);
+        tmp[sizeof(tmp) - 1] = 0;
+        for (char* tok = strtok(tmp, ","); tok && nv < 64; tok = strtok(NULL, ","))
+            vals[nv++] = strtoull(tok, NULL, 10);
+        for (int r = 0; r < g_size; r++)
+            counts[r] = vals[r % nv];
+        }
+    else
+        {
+        fprintf(stderr, "bad dist %s\n", dist);
+        exit(2);
+        }
+    }
+
+static enum pgsd_open_flag parse_flag(const char* s)
+    {
+    if (strcmp(s, "rw") == 0)
+        return PGSD_OPEN_READWRITE;
+    if (strcmp(s, "ro") == 0)
+        return PGSD_OPEN_READONLY;
+    if (strcmp(s, "append") == 0)
+        return PGSD_OPEN_APPEND;
+    fprintf(stderr, "bad flag %s\n", s);
+    exit(2);
+    }
+
+int main(int argc, char** argv)
+    {
+    if (argc < 3)
+        {
+        fprintf(stderr, "usage: %s <script> <out.gsd>\n", argv[0]);
+        return 2;
+        }
+#ifdef PGSD_DRIVER_REF
+    MPI_Init(NULL, NULL);
+    MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &g_size);
+#else
+    if (pgsd_comm_init_from_env() != PGSD_SUCCESS)
+        {
+        fprintf(stderr, "pgsd_comm_init_from_env failed\n");
+        return 3;
+        }
+    g_rank = pgsd_comm_rank();
+    g_size = pgsd_comm_size();
+#endif
+
+    FILE* f = fopen(argv[1], "r");
+    if (!f)
+        {
+        perror(argv[1]);
+        return 2;
+        }
+    const char* path = argv[2];
+
+    struct pgsd_handle handle;
+    uint64_t seed = 1;
+    char line[1024];
+    int lineno = 0;
+    int rc_all = 0;
+    while (fgets(line, sizeof(line), f))
+        {
+        lineno++;
+        char* hash = strchr(line, '#');
+        if (hash)
+            *hash = 0;
+        char* tok[16];
+        int nt = 0;
+        for (char* t = strtok(line, " \t\r\n"); t && nt < 16; t = strtok(NULL, " \t\r\n"))
+            tok[nt++] = t;
+        if (nt == 0)
+            continue;
+        int rc = 0;
+        const char* cmd = tok[0];
+        if (strcmp(cmd, "create") == 0 && nt == 7)
+            {
+            rc = pgsd_create_and_open(&handle, path, tok[1], tok[2],
+                                      pgsd_make_version((unsigned)atoi(tok[3]), (unsigned)atoi(tok[4])),
+                                      parse_flag(tok[5]), atoi(tok[6]));
+            }
+        else if (strcmp(cmd, "open") == 0 && nt == 2)
+            {
+            rc = pgsd_open(&handle, path, parse_flag(tok[1]));
+            }
+        else if (strcmp(cmd, "seed") == 0 && nt == 2)
+            {
+            seed = strtoull(tok[1], NULL, 10);
+            }
+        else if (strcmp(cmd, "chunk") == 0 && nt == 6)
+            {
+            size_t sz;
+            int type = parse_type(tok[2], &sz);
+            uint32_t M = (uint32_t)strtoul(tok[3], NULL, 10);
+            int all = atoi(tok[4]);
+            uint64_t counts[1024];
+            dist_counts(tok[5], counts);
+            uint64_t N = counts[g_rank], Ng = 0, row0 = 0;
+            for (int r = 0; r < g_size; r++)
+                {
+                Ng += counts[r];
+                if (r < g_rank)
+                    row0 += counts[r];
+                }
+            void* data;
+            if (all)
+                {
+                data = gen_data(type, seed, row0, N, M, sz);
+                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M,
+                                      Ng * M, true, 0, data);
+                }
+            else
+                {
+                data = gen_data(type, seed, 0, N, M, sz);
+                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, N, M, 0, N * M,
+                                      false, 0, data);
+                }
+            free(data);
+            }
+        else if (strcmp(cmd, "rawchunk") == 0 && nt == 10)
+            {
+            size_t sz;
+            int type = parse_type(tok[2], &sz);
+            uint64_t N = strtoull(tok[3], NULL, 10);
+            uint32_t M = (uint32_t)strtoul(tok[4], NULL, 10);
+            uint64_t Ng = strtoull(tok[5], NULL, 10);
+            uint32_t Mg = (uint32_t)strtoul(tok[6], NULL, 10);
+            uint64_t off = strtoull(tok[7], NULL, 10);
+            uint64_t gs = strtoull(tok[8], NULL, 10);
+            int all = atoi(tok[9]);
+            void* data = gen_data(type, seed + (uint64_t)g_rank, 0, N, M, sz);
+            rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, Mg, off, gs,
+                                  all != 0, 0, data);
+            free(data);
+            }
+        else if (strcmp(cmd, "end_frame") == 0)
+            rc = pgsd_end_frame(&handle);
+        else if (strcmp(cmd, "flush") == 0)
+            rc = pgsd_flush(&handle);
+        else if (strcmp(cmd, "close") == 0)
+            rc = pgsd_close(&handle);
+        else if (strcmp(cmd, "maxbuf") == 0 && nt == 2)
+            rc = pgsd_set_maximum_write_buffer_size(&handle, strtoull(tok[1], NULL, 10));
+        else if (strcmp(cmd, "idxbuf") == 0 && nt == 2)
+            rc = pgsd_set_index_entries_to_buffer(&handle, strtoull(tok[1], NULL, 10));
+        else if (strcmp(cmd, "dump") == 0)
+            {
+            uint64_t nf = pgsd_get_nframes(&handle);
+            uint64_t nn = pgsd_get_nnames(&handle);
+            if (g_rank == 0)
+                printf("dump line=%d nframes=%" PRIu64 " nnames=%" PRIu64 " file_size=%lld"
+                       " index_location=%" PRIu64 " index_allocated=%" PRIu64
+                       " namelist_location=%" PRIu64 " namelist_allocated=%" PRIu64 "\n",
+                       lineno, nf, nn, (long long)handle.file_size, handle.header.index_location,
+                       handle.header.index_allocated_entries, handle.header.namelist_location,
+                       handle.header.namelist_allocated_entries);
+            }
+        else if (strcmp(cmd, "find") == 0 && nt == 3)
+            {
+            const struct pgsd_index_entry* e
+                = pgsd_find_chunk(&handle, strtoull(tok[1], NULL, 10), tok[2]);
+            if (g_rank == 0)
+                {
+                if (e)
+                    printf("find line=%d frame=%s name=%s N=%" PRIu64 " M=%u type=%u location=%" PRId64
+                           " id=%u\n",
+                           lineno, tok[1], tok[2], e->N, e->M, (unsigned)e->type, e->location,
+                           (unsigned)e->id);
+                else
+                    printf("find line=%d frame=%s name=%s NOTFOUND\n", lineno, tok[1], tok[2]);
+                }
+            }
+        else if (strcmp(cmd, "names") == 0 && nt <= 2)
+            {
+            const char* prefix = nt == 2 ? tok[1] : "";
+            if (g_rank == 0)
+                {
+                const char* p = pgsd_find_matching_chunk_name(&handle, prefix, NULL);
+                printf("names line=%d prefix=%s:", lineno, prefix);
+                while (p)
+                    {
+                    printf(" %s", p);
+                    p = pgsd_find_matching_chunk_name(&handle, prefix, p);
+                    }
+                printf("\n");
+                }
+            }
+        else
+            {
+            fprintf(stderr, "line %d: bad command '%s' (%d tokens)\n", lineno, cmd, nt);
+            return 2;
+            }
+        if (rc != 0)
+            {
+            if (g_rank == 0)
+                printf("rc line=%d cmd=%s rc=%d\n", lineno, cmd, rc);
+            rc_all = rc;
+            }
+        }
+    fclose(f);
+#ifdef PGSD_DRIVER_REF
+    MPI_Finalize();
+#else
+    pgsd_comm_finalize();
+#endif
+    return rc_all ? 1 : 0;
+    }
