@@ -1,0 +1,382 @@
+/* pgsd.h -- C ABI of the MI355X-native PGSD snapshot writer (libpgsd_amd.so).
+ *
+ * Part 1 is the drop-in boundary: the same sixteen entry points, enums and on-disk structs
+ * as the reference's /root/reference/pgsd/pgsd/pgsd.h (each prototype cites the line it
+ * replaces), so a caller of the reference (pgsd/pgsd/fl.pyx, pgsd/scripts/benchmark-write.cc,
+ * HOOMD-SPH's dump writer) re-links without source changes.  Files written through it are
+ * byte-identical to the reference's MPI-IO output for the same calls on the same partition.
+ *
+ * What changed underneath:
+ *   - no <mpi.h>: ranks talk through a small communicator vtable (part 2); back ends are
+ *     "self", a single-node shared-memory segment, RCCL over xGMI, or host callbacks
+ *     (torch.distributed).  The reference's ~10 collectives per chunk become zero for
+ *     per-particle chunks and one 8-byte allgather for replicated small chunks.
+ *   - all metadata (names, index, file size) is replicated deterministically on every
+ *     rank; only rank 0 writes it.  pgsd_find_chunk() is therefore valid on every rank.
+ *   - part 3 adds the device path: chunks are packed from HBM-resident particle arrays
+ *     by HIP kernels, streamed to pinned host slabs with hipMemcpyAsync and written with
+ *     pwrite at the offsets the reference's MPI_File_write_at would use.
+ */
+#ifndef PGSD_H
+#define PGSD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+    {
+#endif
+
+    /* ------------------------------------------------------------------ part 1: drop-in */
+
+    /* element types; reference pgsd.h:38-69 */
+    enum pgsd_type
+        {
+        PGSD_TYPE_UINT8 = 1,
+        PGSD_TYPE_UINT16,
+        PGSD_TYPE_UINT32,
+        PGSD_TYPE_UINT64,
+        PGSD_TYPE_INT8,
+        PGSD_TYPE_INT16,
+        PGSD_TYPE_INT32,
+        PGSD_TYPE_INT64,
+        PGSD_TYPE_FLOAT,
+        PGSD_TYPE_DOUBLE
+        };
+
+    /* reference pgsd.h:72-82 */
+    enum pgsd_open_flag
+        {
+        PGSD_OPEN_READWRITE = 1,
+        PGSD_OPEN_READONLY,
+        PGSD_OPEN_APPEND
+        };
+
+    /* reference pgsd.h:85-120 */
+    enum pgsd_error
+        {
+        PGSD_SUCCESS = 0,
+        PGSD_ERROR_IO = -1,
+        PGSD_ERROR_INVALID_ARGUMENT = -2,
+        PGSD_ERROR_NOT_A_PGSD_FILE = -3,
+        PGSD_ERROR_INVALID_PGSD_FILE_VERSION = -4,
+        PGSD_ERROR_FILE_CORRUPT = -5,
+        PGSD_ERROR_MEMORY_ALLOCATION_FAILED = -6,
+        PGSD_ERROR_NAMELIST_FULL = -7,
+        PGSD_ERROR_FILE_MUST_BE_WRITABLE = -8,
+        PGSD_ERROR_FILE_MUST_BE_READABLE = -9,
+        /* additions (never produced by the reference) */
+        PGSD_ERROR_DEVICE = -20,      /* HIP runtime / kernel failure, see pgsd_last_error_string() */
+        PGSD_ERROR_COMM = -21,        /* communicator failure or ranks disagree */
+        PGSD_ERROR_NO_DEVICE = -22    /* device entry point called without a usable GPU */
+        };
+
+    enum
+        {
+        PGSD_NAME_SIZE = 64, /* reference pgsd.h:122-128 */
+        PGSD_RESERVED_BYTES = 80
+        };
+
+    /* 256-byte file header, on-disk layout; reference pgsd.h:143-174 */
+    struct pgsd_header
+        {
+        uint64_t magic;
+        uint64_t index_location;
+        uint64_t index_allocated_entries;
+        uint64_t namelist_location;
+        uint64_t namelist_allocated_entries;
+        uint32_t schema_version;
+        uint32_t pgsd_version;
+        char application[PGSD_NAME_SIZE];
+        char schema[PGSD_NAME_SIZE];
+        char reserved[PGSD_RESERVED_BYTES];
+        };
+
+    /* 32-byte index entry, on-disk layout; reference pgsd.h:182-204 */
+    struct pgsd_index_entry
+        {
+        uint64_t frame;
+        uint64_t N;
+        int64_t location;
+        uint32_t M;
+        uint16_t id;
+        uint8_t type;
+        uint8_t flags;
+        };
+
+    /* read-only views into library-owned storage; reference pgsd.h:239-286 */
+    struct pgsd_index_buffer
+        {
+        struct pgsd_index_entry* data;
+        size_t size;
+        size_t reserved;
+        };
+
+    struct pgsd_byte_buffer
+        {
+        char* data;
+        size_t size;
+        size_t reserved;
+        };
+
+    struct pgsd_name_buffer
+        {
+        struct pgsd_byte_buffer data;
+        size_t n_names;
+        };
+
+    /* File handle: caller-allocated, by value, zeroed by the library (reference pgsd.h:297-353).
+       The first member of the reference's struct is an MPI_File; here it is a POSIX fd and
+       the library state lives behind `impl`.  Every member is read-only to the caller and
+       is refreshed on return from each pgsd_* call.  The views (file_index, file_names) are
+       valid on EVERY rank until the next call that flushes. */
+    struct pgsd_handle
+        {
+        int fd;
+        struct pgsd_header header;
+        struct pgsd_index_buffer file_index;
+        struct pgsd_name_buffer file_names;
+        uint64_t cur_frame;
+        long long int file_size;
+        enum pgsd_open_flag open_flags;
+        uint64_t pending_index_entries;
+        uint64_t maximum_write_buffer_size;
+        uint64_t index_entries_to_buffer;
+        int rank;
+        int nprocs;
+        void* impl;
+        };
+
+    /* reference pgsd.h:362 */
+    uint32_t pgsd_make_version(unsigned int major, unsigned int minor);
+
+    /* reference pgsd.h:412-418. Collective over the default communicator (part 2). */
+    int pgsd_create_and_open(struct pgsd_handle* handle,
+                             const char* fname,
+                             const char* application,
+                             const char* schema,
+                             uint32_t schema_version,
+                             enum pgsd_open_flag flags,
+                             int exclusive_create);
+
+    /* reference pgsd.h:440 */
+    int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags);
+
+    /* reference pgsd.h:480 */
+    int pgsd_close(struct pgsd_handle* handle);
+
+    /* reference pgsd.h:498. Waits for every device chunk of the frame to reach the file. */
+    int pgsd_end_frame(struct pgsd_handle* handle);
+
+    /* reference pgsd.h:517 */
+    int pgsd_flush(struct pgsd_handle* handle);
+
+    /* reference pgsd.h:551-564.  `data` is HOST memory, borrowed for the call.
+       N/M: this rank's rows/columns; N_global/M_global: what the index entry records;
+       offset: element offset of this rank's first row inside the chunk;
+       global_size: elements in the whole chunk = sum over ranks of N*M (what both in-tree
+       callers pass: fl.pyx:649, benchmark-write.cc:99).  When all==true and global_size==0
+       the sum is obtained with one allgather instead. */
+    int pgsd_write_chunk(struct pgsd_handle* handle,
+                         const char* name,
+                         enum pgsd_type type,
+                         uint64_t N,
+                         uint32_t M,
+                         uint64_t N_global,
+                         uint32_t M_global,
+                         uint64_t offset,
+                         uint64_t global_size,
+                         bool all,
+                         uint8_t flags,
+                         const void* data);
+
+    /* reference pgsd.h:581-582 */
+    const struct pgsd_index_entry*
+    pgsd_find_chunk(struct pgsd_handle* handle, uint64_t frame, const char* name);
+
+    /* reference pgsd.h:604-610 */
+    int pgsd_read_chunk(struct pgsd_handle* handle,
+                        void* data,
+                        const struct pgsd_index_entry* chunk,
+                        uint64_t N,
+                        uint32_t M,
+                        uint32_t offset,
+                        bool all);
+
+    /* reference pgsd.h:620, 630, 638 */
+    uint64_t pgsd_get_nframes(struct pgsd_handle* handle);
+    uint64_t pgsd_get_nnames(struct pgsd_handle* handle);
+    size_t pgsd_sizeof_type(enum pgsd_type type);
+
+    /* reference pgsd.h:659-660 */
+    const char*
+    pgsd_find_matching_chunk_name(struct pgsd_handle* handle, const char* match, const char* prev);
+
+    /* reference pgsd.h:686, 701, 711, 729 */
+    uint64_t pgsd_get_maximum_write_buffer_size(struct pgsd_handle* handle);
+    int pgsd_set_maximum_write_buffer_size(struct pgsd_handle* handle, uint64_t size);
+    uint64_t pgsd_get_index_entries_to_buffer(struct pgsd_handle* handle);
+    int pgsd_set_index_entries_to_buffer(struct pgsd_handle* handle, uint64_t number);
+
+    /* reference pgsd.h:735: broadcast an index entry from rank 0 (unused by the library
+       itself, kept for callers). */
+    void pgsd_bcast_index_entry(struct pgsd_index_entry* e);
+
+    /* Text of the most recent failure on this thread (HIP error strings, comm mismatches). */
+    const char* pgsd_last_error_string(void);
+
+    /* ------------------------------------------------------------ part 2: communicator */
+
+    /* The process-wide default communicator plays the role of the reference's hard-coded
+       MPI_COMM_WORLD (pgsd.c:106-202, 1748).  A handle captures it when it is opened.
+       All ranks must call the collective pgsd_* functions in the same order. */
+    struct pgsd_comm
+        {
+        void* ctx;
+        int rank;
+        int size;
+        /* gather `bytes` bytes from every rank into recv[rank*bytes ...]; 0 on success */
+        int (*allgather)(void* ctx, const void* send, void* recv, size_t bytes);
+        /* optional; NULL = a 1-byte allgather */
+        int (*barrier)(void* ctx);
+        /* optional */
+        void (*destroy)(void* ctx);
+        };
+
+    /* install a caller-provided back end (the struct is copied) */
+    int pgsd_comm_set_default(const struct pgsd_comm* comm);
+    /* single rank (the state after library load) */
+    int pgsd_comm_init_self(void);
+    /* ranks of ONE node through a /dev/shm segment (process-shared barrier + slots) */
+    int pgsd_comm_init_shm(const char* name, int rank, int size);
+    /* PGSD_RANK / PGSD_NRANKS / PGSD_SHM_NAME, else RANK / WORLD_SIZE / MASTER_PORT
+       (torchrun), else self */
+    int pgsd_comm_init_from_env(void);
+    /* RCCL over xGMI: `unique_id` is the 128-byte ncclUniqueId created by
+       pgsd_comm_rccl_unique_id() on one rank and distributed by the caller.  Allgathers run
+       as ncclAllGather on device buffers on a private HIP stream. */
+    int pgsd_comm_rccl_unique_id(void* unique_id_128);
+    int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device);
+    int pgsd_comm_finalize(void);
+    int pgsd_comm_rank(void);
+    int pgsd_comm_size(void);
+    int pgsd_comm_allgather(const void* send, void* recv, size_t bytes);
+    int pgsd_comm_barrier(void);
+
+    /* The per-frame exchange of the reference's callers (benchmark-write.cc:39-45,
+       fl.pyx:596-598): allgather every rank's local row count; returns the exclusive
+       prefix (this rank's first row) and the total.  counts may be NULL. */
+    int pgsd_partition_rows(uint64_t n_local, uint64_t* row0, uint64_t* n_global, uint64_t* counts);
+
+    /* --------------------------------------------------------------- part 3: device path */
+
+    /* One output chunk fed from an HBM-resident source array:
+         chunk[i][c] = convert(src[(order ? order[i] : i) * src_stride + src_col0 + c]),
+         i < N, c < M, converted from src_type to the chunk's pgsd_type.
+       Supported conversions: same type; integer<->integer (wrap / extend by source
+       signedness); f64->f32 (round to nearest even); f32->f64; <=32-bit integer->float;
+       bitcast (low bytes of the element unchanged, e.g. HOOMD's typeid kept in position.w). */
+    struct pgsd_field_desc
+        {
+        const void* src;       /* device pointer */
+        const uint32_t* order; /* device pointer or NULL */
+        uint32_t src_type;     /* enum pgsd_type */
+        uint32_t src_stride;   /* elements per source row (4 for float4 / double4) */
+        uint32_t src_col0;     /* first source column */
+        uint32_t bitcast;      /* 0 = value conversion, 1 = reinterpret low bytes */
+        };
+
+    /* Device twin of pgsd_write_chunk: same arguments, but the rows come from device
+       memory described by `src`.  Host bookkeeping (name, index entry, file location) is
+       done before returning; the pack kernel, the device->pinned-host copy and the pwrite
+       run asynchronously and are complete when pgsd_end_frame() returns.  The source
+       arrays must stay unmodified until pgsd_device_wait_packed() or pgsd_end_frame(). */
+    int pgsd_write_chunk_device(struct pgsd_handle* handle,
+                                const char* name,
+                                enum pgsd_type type,
+                                uint64_t N,
+                                uint32_t M,
+                                uint64_t N_global,
+                                uint32_t M_global,
+                                uint64_t offset,
+                                uint64_t global_size,
+                                bool all,
+                                uint8_t flags,
+                                const struct pgsd_field_desc* src);
+
+    /* Several per-particle chunks (all==true, same N / N_global / row offset) packed by ONE
+       fused kernel launch, e.g. position+velocity+typeid. offset_rows is this rank's first
+       row (elements = offset_rows * M per chunk). */
+    struct pgsd_chunk_req
+        {
+        const char* name;
+        uint32_t type; /* enum pgsd_type of the chunk */
+        uint32_t M;
+        struct pgsd_field_desc src;
+        };
+    int pgsd_write_chunks_device(struct pgsd_handle* handle,
+                                 uint32_t n_chunks,
+                                 const struct pgsd_chunk_req* chunks,
+                                 uint64_t N,
+                                 uint64_t N_global,
+                                 uint64_t offset_rows);
+
+    /* Block until every pack kernel issued for the open frame has finished (the source
+       arrays may be overwritten again); copies and file writes keep running. */
+    int pgsd_device_wait_packed(struct pgsd_handle* handle);
+
+    struct pgsd_device_config
+        {
+        int device;             /* HIP device ordinal; -1 = current */
+        uint64_t slab_bytes;    /* pinned host staging slab size (default 32 MiB) */
+        uint32_t n_slabs;       /* slabs in the ring (default 8) */
+        uint32_t n_writers;     /* pwrite threads (default 8) */
+        uint32_t profile;       /* 1 = bracket every pack launch with HIP events */
+        uint32_t reserved;
+        };
+    int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg);
+
+    struct pgsd_device_stats
+        {
+        uint64_t pack_launches;     /* kernels launched since open / last reset */
+        double pack_ms;             /* sum of event-timed kernel durations (profile=1) */
+        uint64_t pack_rows;         /* rows (particles) packed, summed over launches */
+        uint64_t pack_bytes_out;    /* chunk bytes produced */
+        uint64_t pack_bytes_in;     /* source bytes the kernels had to read (algorithmic) */
+        uint64_t d2h_bytes;
+        uint64_t written_bytes;
+        double d2h_ms;              /* sum of event-timed copy durations (profile=1) */
+        double write_ms;            /* sum of pwrite wall time over writer threads */
+        };
+    int pgsd_device_get_stats(struct pgsd_handle* handle, struct pgsd_device_stats* out, int reset);
+
+    /* Bare kernels, no file: pack into caller-provided device buffers on `stream`
+       (a hipStream_t passed as void*; NULL = the null stream).  Used by the parity tests and
+       by bench.py's roofline leg. */
+    struct pgsd_pack_job
+        {
+        void* dst;         /* device pointer, N*M elements of dst_type, 16-byte aligned */
+        uint32_t dst_type; /* enum pgsd_type */
+        uint32_t M;
+        struct pgsd_field_desc src;
+        };
+    int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream);
+
+    /* Stream compaction for filtered snapshots: out_index[k] = i for the k-th row whose
+       flag byte is non-zero (stable), *out_count (device uint64) = number selected.
+       Wavefront ballot/popcount scans + one cross-block pass. `workspace` must hold
+       pgsd_select_workspace_bytes(N) bytes. */
+    size_t pgsd_select_workspace_bytes(uint64_t N);
+    int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
+                         void* workspace, void* stream);
+
+    /* 1 when a gfx950-capable HIP device is visible to this process */
+    int pgsd_device_available(void);
+
+#ifdef __cplusplus
+    }
+#endif
+
+#endif /* PGSD_H */

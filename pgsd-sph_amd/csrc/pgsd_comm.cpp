@@ -1,0 +1,329 @@
+// pgsd_comm.cpp -- process-wide default communicator and its host back ends.
+//
+// Replaces the reference's hard-coded MPI_COMM_WORLD (pgsd.c:106-202, 1748).  The only
+// primitive the file layer needs is a small allgather; barrier and broadcast are built
+// from it.  Back ends here: "self" (one rank) and "shm" (ranks of one node meeting in a
+// /dev/shm segment: process-shared pthread barrier + one 4 KiB slot per rank).  The RCCL
+// back end lives in pgsd_comm_rccl.cpp, host-callback back ends are installed with
+// pgsd_comm_set_default().
+#include "pgsd_internal.hpp"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <pthread.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+namespace pgsd_amd
+    {
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& s)
+    {
+    g_last_error = s;
+    }
+
+const char* last_error()
+    {
+    return g_last_error.c_str();
+    }
+
+// ---------------------------------------------------------------- self
+static int self_allgather(void*, const void* send, void* recv, size_t bytes)
+    {
+    if (send != recv)
+        memcpy(recv, send, bytes);
+    return 0;
+    }
+
+static pgsd_comm make_self()
+    {
+    pgsd_comm c;
+    memset(&c, 0, sizeof(c));
+    c.rank = 0;
+    c.size = 1;
+    c.allgather = self_allgather;
+    return c;
+    }
+
+static pgsd_comm g_comm = make_self();
+
+pgsd_comm default_comm()
+    {
+    return g_comm;
+    }
+
+// ---------------------------------------------------------------- shm
+enum
+    {
+    SHM_SLOT_BYTES = 4096,
+    SHM_MAGIC = 0x50475344 // "PGSD"
+    };
+
+struct ShmSegment
+    {
+    volatile uint32_t ready;
+    uint32_t size;
+    pthread_barrier_t barrier;
+    char pad[64];
+    // followed by size * SHM_SLOT_BYTES slot bytes
+    };
+
+struct ShmCtx
+    {
+    ShmSegment* seg;
+    char* slots;
+    size_t map_bytes;
+    std::string name;
+    int rank, size;
+    };
+
+static int shm_barrier(void* p)
+    {
+    ShmCtx* c = (ShmCtx*)p;
+    int rv = pthread_barrier_wait(&c->seg->barrier);
+    return (rv == 0 || rv == PTHREAD_BARRIER_SERIAL_THREAD) ? 0 : -1;
+    }
+
+static int shm_allgather(void* p, const void* send, void* recv, size_t bytes)
+    {
+    ShmCtx* c = (ShmCtx*)p;
+    const char* s = (const char*)send;
+    char* r = (char*)recv;
+    // messages larger than a slot go in rounds
+    size_t done = 0;
+    do
+        {
+        size_t n = bytes - done < (size_t)SHM_SLOT_BYTES ? bytes - done : (size_t)SHM_SLOT_BYTES;
+        memcpy(c->slots + (size_t)c->rank * SHM_SLOT_BYTES, s + done, n);
+        if (shm_barrier(p) != 0)
+            return -1;
+        for (int j = 0; j < c->size; j++)
+            memcpy(r + (size_t)j * bytes + done, c->slots + (size_t)j * SHM_SLOT_BYTES, n);
+        if (shm_barrier(p) != 0)
+            return -1;
+        done += n;
+        } while (done < bytes);
+    return 0;
+    }
+
+static void shm_destroy(void* p)
+    {
+    ShmCtx* c = (ShmCtx*)p;
+    // everyone is past its last use before rank 0 removes the name
+    pthread_barrier_wait(&c->seg->barrier);
+    munmap((void*)c->seg, c->map_bytes);
+    if (c->rank == 0)
+        shm_unlink(c->name.c_str());
+    delete c;
+    }
+
+static int comm_install(const pgsd_comm& c)
+    {
+    if (g_comm.destroy)
+        g_comm.destroy(g_comm.ctx);
+    g_comm = c;
+    return PGSD_SUCCESS;
+    }
+    } // namespace pgsd_amd
+
+using namespace pgsd_amd;
+
+extern "C" const char* pgsd_last_error_string(void)
+    {
+    return last_error();
+    }
+
+extern "C" int pgsd_comm_set_default(const struct pgsd_comm* comm)
+    {
+    if (!comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    return comm_install(*comm);
+    }
+
+extern "C" int pgsd_comm_init_self(void)
+    {
+    return comm_install(make_self());
+    }
+
+extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
+    {
+    if (!name || size < 1 || rank < 0 || rank >= size)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (size == 1)
+        return pgsd_comm_init_self();
+    std::string nm = name[0] == '/' ? name : std::string("/") + name;
+    size_t bytes = sizeof(ShmSegment) + (size_t)size * SHM_SLOT_BYTES;
+    int fd = -1;
+    if (rank == 0)
+        {
+        shm_unlink(nm.c_str()); // stale segment of a crashed run
+        fd = shm_open(nm.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0)
+            {
+            set_last_error("shm_open/ftruncate failed for " + nm + ": " + strerror(errno));
+            if (fd >= 0)
+                close(fd);
+            return PGSD_ERROR_COMM;
+            }
+        }
+    else
+        {
+        // wait (up to ~60 s) for rank 0 to create and size the segment
+        struct timespec ts = {0, 2000000};
+        for (int tries = 0; tries < 30000; tries++)
+            {
+            fd = shm_open(nm.c_str(), O_RDWR, 0600);
+            if (fd >= 0)
+                {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes)
+                    break;
+                close(fd);
+                fd = -1;
+                }
+            nanosleep(&ts, NULL);
+            }
+        if (fd < 0)
+            {
+            set_last_error("timed out waiting for shm segment " + nm);
+            return PGSD_ERROR_COMM;
+            }
+        }
+    void* m = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED)
+        {
+        set_last_error(std::string("mmap of shm segment failed: ") + strerror(errno));
+        return PGSD_ERROR_COMM;
+        }
+    ShmSegment* seg = (ShmSegment*)m;
+    if (rank == 0)
+        {
+        pthread_barrierattr_t attr;
+        pthread_barrierattr_init(&attr);
+        pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+        pthread_barrier_init(&seg->barrier, &attr, (unsigned)size);
+        pthread_barrierattr_destroy(&attr);
+        seg->size = (uint32_t)size;
+        __sync_synchronize();
+        seg->ready = SHM_MAGIC;
+        }
+    else
+        {
+        struct timespec ts = {0, 1000000};
+        int tries = 0;
+        while (seg->ready != SHM_MAGIC && tries++ < 60000)
+            nanosleep(&ts, NULL);
+        __sync_synchronize();
+        if (seg->ready != SHM_MAGIC || seg->size != (uint32_t)size)
+            {
+            munmap(m, bytes);
+            set_last_error("shm segment " + nm + " not initialised or size mismatch");
+            return PGSD_ERROR_COMM;
+            }
+        }
+    ShmCtx* c = new ShmCtx;
+    c->seg = seg;
+    c->slots = (char*)m + sizeof(ShmSegment);
+    c->map_bytes = bytes;
+    c->name = nm;
+    c->rank = rank;
+    c->size = size;
+    pgsd_comm pc;
+    memset(&pc, 0, sizeof(pc));
+    pc.ctx = c;
+    pc.rank = rank;
+    pc.size = size;
+    pc.allgather = shm_allgather;
+    pc.barrier = shm_barrier;
+    pc.destroy = shm_destroy;
+    return comm_install(pc);
+    }
+
+extern "C" int pgsd_comm_init_from_env(void)
+    {
+    const char* r = getenv("PGSD_RANK");
+    const char* n = getenv("PGSD_NRANKS");
+    const char* nm = getenv("PGSD_SHM_NAME");
+    if (r && n)
+        {
+        std::string name = nm ? nm : "pgsd_amd_default";
+        return pgsd_comm_init_shm(name.c_str(), atoi(r), atoi(n));
+        }
+    r = getenv("RANK");
+    n = getenv("WORLD_SIZE");
+    if (r && n && atoi(n) > 1)
+        {
+        const char* port = getenv("MASTER_PORT");
+        std::string name = std::string("pgsd_amd_") + (port ? port : "0");
+        return pgsd_comm_init_shm(name.c_str(), atoi(r), atoi(n));
+        }
+    return pgsd_comm_init_self();
+    }
+
+extern "C" int pgsd_comm_finalize(void)
+    {
+    return comm_install(make_self());
+    }
+
+extern "C" int pgsd_comm_rank(void)
+    {
+    return default_comm().rank;
+    }
+
+extern "C" int pgsd_comm_size(void)
+    {
+    return default_comm().size;
+    }
+
+extern "C" int pgsd_comm_allgather(const void* send, void* recv, size_t bytes)
+    {
+    pgsd_comm c = default_comm();
+    return c.allgather(c.ctx, send, recv, bytes) == 0 ? PGSD_SUCCESS : PGSD_ERROR_COMM;
+    }
+
+extern "C" int pgsd_comm_barrier(void)
+    {
+    pgsd_comm c = default_comm();
+    return comm_barrier(c);
+    }
+
+extern "C" int pgsd_partition_rows(uint64_t n_local, uint64_t* row0, uint64_t* n_global, uint64_t* counts)
+    {
+    pgsd_comm c = default_comm();
+    std::vector<uint64_t> all((size_t)c.size);
+    if (c.allgather(c.ctx, &n_local, all.data(), sizeof(uint64_t)) != 0)
+        return PGSD_ERROR_COMM;
+    uint64_t before = 0, total = 0;
+    for (int j = 0; j < c.size; j++)
+        {
+        if (j < c.rank)
+            before += all[(size_t)j];
+        total += all[(size_t)j];
+        if (counts)
+            counts[j] = all[(size_t)j];
+        }
+    if (row0)
+        *row0 = before;
+    if (n_global)
+        *n_global = total;
+    return PGSD_SUCCESS;
+    }
+
+// reference pgsd.h:735 / pgsd.c:152-172: broadcast of one index entry from rank 0
+extern "C" void pgsd_bcast_index_entry(struct pgsd_index_entry* e)
+    {
+    if (!e)
+        return;
+    pgsd_comm c = default_comm();
+    std::vector<pgsd_index_entry> all((size_t)c.size);
+    if (c.allgather(c.ctx, e, all.data(), sizeof(*e)) == 0)
+        *e = all[0];
+    }

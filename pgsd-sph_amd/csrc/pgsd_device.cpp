@@ -1,0 +1,538 @@
+// pgsd_device.cpp -- the HBM -> file pipeline behind pgsd_write_chunk_device().
+//
+//   pack stream   fused pack kernel(s) write dense chunk bytes into a device staging arena
+//                 (one kernel per submit; the arena holds a whole frame: 288 GB of HBM make
+//                 a 0.3-1.6 GB snapshot copy cheap, and the simulation only has to wait for
+//                 the ~100 us pack, not for the file write)
+//   copy stream   waits for the pack event, then streams the staged bytes piece by piece
+//                 into a ring of pinned host slabs with hipMemcpyAsync (SDMA engine), so
+//                 the copy of piece k+1 overlaps the file write of piece k and the pack
+//                 of the next chunk
+//   writer pool   each piece is pwrite()n at the file offset the reference's
+//                 MPI_File_write_at would use (pgsd.c:2225-2229) as soon as its copy event
+//                 has fired; the slab then returns to the ring
+//
+// pgsd_end_frame()/pgsd_flush() call drain(): the frame is in the file when it returns.
+#include "pgsd_internal.hpp"
+#include "pgsd_pack.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace pgsd_amd
+    {
+#define HIP_TRY(expr)                                                                      \
+    do                                                                                     \
+        {                                                                                  \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            {                                                                              \
+            fail(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            return PGSD_ERROR_DEVICE;                                                      \
+            }                                                                              \
+        } while (0)
+
+class DevicePipeline
+    {
+    public:
+    DevicePipeline(const pgsd_device_config& cfg, int fd) : m_cfg(cfg), m_fd(fd) { }
+
+    int init()
+        {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            {
+            (void)hipGetLastError();
+            fail("no HIP device visible: the device path has no CPU fallback");
+            return PGSD_ERROR_NO_DEVICE;
+            }
+        if (m_cfg.device < 0)
+            HIP_TRY(hipGetDevice(&m_cfg.device));
+        HIP_TRY(hipSetDevice(m_cfg.device));
+        if (m_cfg.slab_bytes == 0)
+            m_cfg.slab_bytes = (uint64_t)16 << 20;
+        if (m_cfg.n_slabs == 0)
+            m_cfg.n_slabs = 16;
+        if (m_cfg.n_writers == 0)
+            m_cfg.n_writers = 8;
+        HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
+        m_slabs.resize(m_cfg.n_slabs);
+        for (auto& s : m_slabs)
+            {
+            HIP_TRY(hipHostMalloc((void**)&s.host, m_cfg.slab_bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+            }
+        for (uint32_t i = 0; i < m_cfg.n_slabs; i++)
+            m_free_slabs.push_back(i);
+        m_pool = writer_pool_create(m_cfg.n_writers);
+        m_dispatcher = std::thread([this] { dispatch_loop(); });
+        m_ok = true;
+        return PGSD_SUCCESS;
+        }
+
+    ~DevicePipeline()
+        {
+        if (m_dispatcher.joinable())
+            {
+                {
+                std::lock_guard<std::mutex> g(m_mutex);
+                m_stop = true;
+                }
+            m_cv_jobs.notify_all();
+            m_cv_slabs.notify_all();
+            m_dispatcher.join();
+            }
+        if (m_pool)
+            writer_pool_destroy(m_pool); // joins the writers
+        (void)hipSetDevice(m_cfg.device);
+        release_events();
+        for (auto& s : m_slabs)
+            {
+            if (s.copied)
+                (void)hipEventDestroy(s.copied);
+            if (s.host)
+                (void)hipHostFree(s.host);
+            }
+        for (auto& a : m_arenas)
+            (void)hipFree(a.base);
+        if (m_pack_stream)
+            (void)hipStreamDestroy(m_pack_stream);
+        if (m_copy_stream)
+            (void)hipStreamDestroy(m_copy_stream);
+        }
+
+    int submit(std::vector<DeviceChunk>& chunks, uint64_t N)
+        {
+        if (!m_ok)
+            return PGSD_ERROR_NO_DEVICE;
+        if (failed())
+            return PGSD_ERROR_DEVICE;
+        HIP_TRY(hipSetDevice(m_cfg.device));
+
+        std::vector<pgsd_pack_job> jobs;
+        uint64_t bytes_in = 0, bytes_out = 0;
+        for (auto& c : chunks)
+            {
+            size_t bytes = (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type));
+            void* stage = nullptr;
+            int rc = arena_alloc(bytes, &stage);
+            if (rc != PGSD_SUCCESS)
+                return rc;
+            c.job.dst = stage;
+            jobs.push_back(c.job);
+            bytes_in += pack_algorithmic_bytes_in(c.job, c.N);
+            bytes_out += bytes;
+            }
+
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (m_cfg.profile)
+            {
+            HIP_TRY(hipEventCreate(&ev0));
+            HIP_TRY(hipEventCreate(&ev1));
+            HIP_TRY(hipEventRecord(ev0, m_pack_stream));
+            }
+        std::string err;
+        int rc = launch_pack((uint32_t)jobs.size(), jobs.data(), N, m_pack_stream, &err);
+        if (rc != PGSD_SUCCESS)
+            {
+            fail(err);
+            return rc;
+            }
+        if (m_cfg.profile)
+            {
+            HIP_TRY(hipEventRecord(ev1, m_pack_stream));
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_pack_events.push_back({ev0, ev1});
+            }
+        hipEvent_t packed;
+        HIP_TRY(hipEventCreateWithFlags(&packed, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(packed, m_pack_stream));
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_misc_events.push_back(packed);
+            m_stats.pack_launches++;
+            m_stats.pack_rows += N;
+            m_stats.pack_bytes_in += bytes_in;
+            m_stats.pack_bytes_out += bytes_out;
+            }
+
+        for (auto& c : chunks)
+            {
+            size_t bytes = (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type));
+            if (c.host_dst)
+                {
+                // small replicated chunk headed for the write buffer: synchronous
+                HIP_TRY(hipStreamSynchronize(m_pack_stream));
+                HIP_TRY(hipMemcpy(c.host_dst, c.job.dst, bytes, hipMemcpyDeviceToHost));
+                }
+            else
+                {
+                CopyJob j;
+                j.dsrc = (const char*)c.job.dst;
+                j.bytes = bytes;
+                j.file_offset = c.file_offset;
+                j.packed = packed;
+                size_t pieces = (bytes + m_cfg.slab_bytes - 1) / m_cfg.slab_bytes;
+                    {
+                    std::lock_guard<std::mutex> g(m_mutex);
+                    m_outstanding += pieces;
+                    m_jobs.push_back(j);
+                    }
+                m_cv_jobs.notify_one();
+                }
+            }
+        return PGSD_SUCCESS;
+        }
+
+    int wait_packed()
+        {
+        if (!m_ok)
+            return PGSD_SUCCESS;
+        HIP_TRY(hipSetDevice(m_cfg.device));
+        HIP_TRY(hipStreamSynchronize(m_pack_stream));
+        return failed() ? PGSD_ERROR_DEVICE : PGSD_SUCCESS;
+        }
+
+    // every submitted byte is in the file (or an error is reported); staging is recycled
+    int drain()
+        {
+        if (!m_ok)
+            {
+            return PGSD_SUCCESS;
+            }
+            {
+            std::unique_lock<std::mutex> lk(m_mutex);
+            m_cv_done.wait(lk, [this] { return m_outstanding == 0 || !m_error.empty(); });
+            }
+        (void)hipSetDevice(m_cfg.device);
+        hipError_t e = hipStreamSynchronize(m_pack_stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(m_copy_stream);
+        if (e != hipSuccess)
+            fail(std::string("stream synchronize: ") + hipGetErrorString(e));
+        collect_timings();
+        release_events();
+        for (auto& a : m_arenas)
+            a.used = 0;
+        if (failed())
+            {
+            // let the writers finish what they hold before the caller tears anything down
+            std::unique_lock<std::mutex> lk(m_mutex);
+            m_cv_done.wait_for(lk, std::chrono::seconds(30), [this] { return m_outstanding == 0; });
+            return m_io_error ? PGSD_ERROR_IO : PGSD_ERROR_DEVICE;
+            }
+        return PGSD_SUCCESS;
+        }
+
+    bool idle()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        return m_outstanding == 0;
+        }
+
+    void stats(pgsd_device_stats* out, int reset)
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        *out = m_stats;
+        if (reset)
+            memset(&m_stats, 0, sizeof(m_stats));
+        }
+
+    std::string error()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        return m_error;
+        }
+
+    private:
+    struct Slab
+        {
+        char* host = nullptr;
+        hipEvent_t copied = nullptr;
+        };
+    struct Arena
+        {
+        char* base;
+        size_t cap, used;
+        };
+    struct CopyJob
+        {
+        const char* dsrc;
+        size_t bytes;
+        long long file_offset;
+        hipEvent_t packed;
+        };
+
+    void fail(const std::string& msg, bool io = false)
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        if (m_error.empty())
+            {
+            m_error = msg;
+            m_io_error = io;
+            }
+        m_cv_done.notify_all();
+        m_cv_slabs.notify_all();
+        }
+
+    bool failed()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        return !m_error.empty();
+        }
+
+    int arena_alloc(size_t bytes, void** out)
+        {
+        size_t need = (bytes + 255) & ~(size_t)255;
+        if (need == 0)
+            need = 256;
+        for (auto& a : m_arenas)
+            if (a.cap - a.used >= need)
+                {
+                *out = a.base + a.used;
+                a.used += need;
+                return PGSD_SUCCESS;
+                }
+        size_t cap = std::max(need, (size_t)256 << 20);
+        Arena a;
+        a.base = nullptr;
+        HIP_TRY(hipMalloc((void**)&a.base, cap));
+        a.cap = cap;
+        a.used = need;
+        m_arenas.push_back(a);
+        *out = a.base;
+        return PGSD_SUCCESS;
+        }
+
+    void release_events()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        for (auto& p : m_pack_events)
+            {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+            }
+        m_pack_events.clear();
+        for (auto& p : m_copy_events)
+            {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+            }
+        m_copy_events.clear();
+        for (auto e : m_misc_events)
+            (void)hipEventDestroy(e);
+        m_misc_events.clear();
+        }
+
+    void collect_timings()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        for (auto& p : m_pack_events)
+            {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+                m_stats.pack_ms += ms;
+            }
+        for (auto& p : m_copy_events)
+            {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+                m_stats.d2h_ms += ms;
+            }
+        }
+
+    // feeds the copy stream: one hipMemcpyAsync per slab-sized piece
+    void dispatch_loop()
+        {
+        (void)hipSetDevice(m_cfg.device);
+        for (;;)
+            {
+            CopyJob job;
+                {
+                std::unique_lock<std::mutex> lk(m_mutex);
+                m_cv_jobs.wait(lk, [this] { return m_stop || !m_jobs.empty(); });
+                if (m_jobs.empty())
+                    return;
+                job = m_jobs.front();
+                m_jobs.pop_front();
+                }
+            bool bad = failed();
+            if (!bad && hipStreamWaitEvent(m_copy_stream, job.packed, 0) != hipSuccess)
+                {
+                fail("hipStreamWaitEvent failed");
+                bad = true;
+                }
+            hipEvent_t c0 = nullptr, c1 = nullptr;
+            if (!bad && m_cfg.profile)
+                {
+                if (hipEventCreate(&c0) == hipSuccess && hipEventCreate(&c1) == hipSuccess)
+                    (void)hipEventRecord(c0, m_copy_stream);
+                }
+            for (size_t off = 0; off < job.bytes; off += m_cfg.slab_bytes)
+                {
+                size_t n = std::min((size_t)m_cfg.slab_bytes, job.bytes - off);
+                if (bad || failed())
+                    {
+                    bad = true;
+                    piece_done(0, 0);
+                    continue;
+                    }
+                int si = -1;
+                    {
+                    std::unique_lock<std::mutex> lk(m_mutex);
+                    m_cv_slabs.wait(lk, [this] { return m_stop || !m_free_slabs.empty() || !m_error.empty(); });
+                    if (!m_free_slabs.empty() && m_error.empty())
+                        {
+                        si = (int)m_free_slabs.front();
+                        m_free_slabs.pop_front();
+                        }
+                    }
+                if (si < 0)
+                    {
+                    bad = true;
+                    piece_done(0, 0);
+                    continue;
+                    }
+                Slab& s = m_slabs[(size_t)si];
+                hipError_t e = hipMemcpyAsync(s.host, job.dsrc + off, n, hipMemcpyDeviceToHost, m_copy_stream);
+                if (e == hipSuccess)
+                    e = hipEventRecord(s.copied, m_copy_stream);
+                if (e != hipSuccess)
+                    {
+                    fail(std::string("hipMemcpyAsync D2H: ") + hipGetErrorString(e));
+                    release_slab(si);
+                    bad = true;
+                    piece_done(0, 0);
+                    continue;
+                    }
+                long long foff = job.file_offset + (long long)off;
+                writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
+                }
+            if (c0 && c1)
+                {
+                (void)hipEventRecord(c1, m_copy_stream);
+                std::lock_guard<std::mutex> g(m_mutex);
+                m_copy_events.push_back({c0, c1});
+                }
+            }
+        }
+
+    void write_piece(int si, size_t n, long long foff)
+        {
+        (void)hipSetDevice(m_cfg.device);
+        Slab& s = m_slabs[(size_t)si];
+        hipError_t e = hipEventSynchronize(s.copied);
+        double ms = 0;
+        if (e != hipSuccess)
+            fail(std::string("hipEventSynchronize(copy): ") + hipGetErrorString(e));
+        else
+            {
+            auto t0 = std::chrono::steady_clock::now();
+            int w = pwrite_full(m_fd, s.host, n, foff);
+            ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (w != 0)
+                fail(std::string("pwrite: ") + strerror(-w), true);
+            }
+        release_slab(si);
+        piece_done(n, ms);
+        }
+
+    void release_slab(int si)
+        {
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_free_slabs.push_back((uint32_t)si);
+            }
+        m_cv_slabs.notify_one();
+        }
+
+    void piece_done(size_t n, double write_ms)
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        m_stats.d2h_bytes += n;
+        m_stats.written_bytes += n;
+        m_stats.write_ms += write_ms;
+        if (--m_outstanding == 0)
+            m_cv_done.notify_all();
+        }
+
+    pgsd_device_config m_cfg;
+    int m_fd;
+    bool m_ok = false;
+    hipStream_t m_pack_stream = nullptr, m_copy_stream = nullptr;
+    std::vector<Slab> m_slabs;
+    std::deque<uint32_t> m_free_slabs;
+    std::vector<Arena> m_arenas;
+    std::deque<CopyJob> m_jobs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pack_events, m_copy_events;
+    std::vector<hipEvent_t> m_misc_events;
+    WriterPool* m_pool = nullptr;
+    std::thread m_dispatcher;
+    std::mutex m_mutex;
+    std::condition_variable m_cv_jobs, m_cv_slabs, m_cv_done;
+    size_t m_outstanding = 0;
+    bool m_stop = false;
+    std::string m_error;
+    bool m_io_error = false;
+    pgsd_device_stats m_stats = {};
+    };
+
+DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, std::string* err)
+    {
+    DevicePipeline* p = new DevicePipeline(cfg, fd);
+    if (p->init() != PGSD_SUCCESS)
+        {
+        if (err)
+            *err = p->error();
+        delete p;
+        return nullptr;
+        }
+    return p;
+    }
+
+void device_pipeline_destroy(DevicePipeline* p)
+    {
+    delete p;
+    }
+
+int device_pipeline_submit(DevicePipeline* p, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err)
+    {
+    int rc = p->submit(chunks, N);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_wait_packed(DevicePipeline* p, std::string* err)
+    {
+    int rc = p->wait_packed();
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_drain(DevicePipeline* p, std::string* err)
+    {
+    int rc = p->drain();
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+void device_pipeline_stats(DevicePipeline* p, pgsd_device_stats* out, int reset)
+    {
+    p->stats(out, reset);
+    }
+
+bool device_pipeline_idle(DevicePipeline* p)
+    {
+    return p->idle();
+    }
+    } // namespace pgsd_amd

@@ -1,0 +1,1358 @@
+// pgsd_file.cpp -- the GSD v2 container writer/reader behind the pgsd.h C ABI.
+//
+// Produces, for the same sequence of calls on the same particle partition, exactly the
+// bytes the reference's MPI-IO implementation produces (/root/reference/pgsd/pgsd/pgsd.c;
+// the functions below cite the lines whose on-disk effect they reproduce).  The protocol
+// between ranks is different by design:
+//
+//   reference                                   here
+//   ---------                                   ----
+//   names / index / buffer_index on rank 0      replicated on every rank (same calls in the
+//   only, scalars re-broadcast after each step    same order => same state), rank 0 writes them
+//   4 barriers + 3 allreduces + 2 bcasts per    per-particle chunk (all=true): none
+//   chunk (pgsd.c:2143-2257)                    replicated chunk (all=false): one 8-byte allgather
+//   ~15 collectives per pgsd_flush              one status allgather (+ one EOF exchange when
+//                                                 the on-disk index is relocated)
+//   MPI_File_write_at                           pwrite at the identical offset, split over a
+//                                                 writer pool; device chunks arrive through
+//                                                 the HIP pipeline (pgsd_device.cpp)
+#include "pgsd_internal.hpp"
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <unordered_map>
+#include <vector>
+
+namespace pgsd_amd
+    {
+// constants of the format / reference defaults, pgsd.c:54-102
+static const uint64_t MAGIC_ID = 0x65DF65DF65DF65DFull;
+enum
+    {
+    INITIAL_INDEX_SIZE = 128,
+    INITIAL_NAME_BUFFER_SIZE = 1024,
+    INITIAL_FRAME_NAMES_SIZE = 64,
+    CURRENT_FILE_VERSION = 2
+    };
+static const uint64_t DEFAULT_MAXIMUM_WRITE_BUFFER_SIZE = 64ull * 1024 * 1024;
+static const uint64_t DEFAULT_INDEX_ENTRIES_TO_BUFFER = 256ull * 1024;
+static const uint64_t INDEX_COPY_ENTRIES = 256ull * 1024;
+
+static_assert(sizeof(pgsd_header) == 256, "GSD header is 256 bytes on disk");
+static_assert(sizeof(pgsd_index_entry) == 32, "GSD index entry is 32 bytes on disk");
+
+size_t sizeof_type(uint32_t type)
+    {
+    static const size_t s[] = {0, 1, 2, 4, 8, 1, 2, 4, 8, 4, 8}; // pgsd.c:2539-2555
+    return (type >= 1 && type <= 10) ? s[type] : 0;
+    }
+
+static uint32_t make_version(unsigned major, unsigned minor)
+    {
+    return major << 16 | minor; // pgsd.c:1705-1708
+    }
+
+// Byte buffer whose capacity doubles the way pgsd_byte_buffer_append does (pgsd.c:490-525).
+// The capacity of the name list is observable: it decides when the namelist block is
+// relocated to the end of the file and how many bytes are rewritten.
+struct ByteBuf
+    {
+    std::vector<char> d; // d.size() is the "reserved" of the reference
+    size_t size = 0;
+
+    void allocate(size_t reserve)
+        {
+        d.assign(reserve, 0);
+        size = 0;
+        }
+
+    size_t reserved() const
+        {
+        return d.size();
+        }
+
+    void append(const char* data, size_t n)
+        {
+        if (n == 0)
+            return;
+        if (size + n > d.size())
+            {
+            size_t nr = d.size() * 2;
+            while (size + n >= nr)
+                nr *= 2;
+            d.resize(nr, 0);
+            }
+        memcpy(d.data() + size, data, n);
+        size += n;
+        }
+    };
+
+static int cmp_entry(const pgsd_index_entry& a, const pgsd_index_entry& b)
+    {
+    // pgsd.c:799-833
+    if (a.frame < b.frame)
+        return -1;
+    if (a.frame > b.frame)
+        return 1;
+    if (a.id < b.id)
+        return -1;
+    if (a.id > b.id)
+        return 1;
+    return 0;
+    }
+
+// In-place heap sort in the reference's exact order of swaps (pgsd.c:839-953): the sort is
+// not stable, so the position of entries with equal (frame, id) is part of the file bytes.
+static void sift_down(std::vector<pgsd_index_entry>& v, size_t start, size_t end)
+    {
+    size_t root = start;
+    while (2 * root + 1 <= end)
+        {
+        size_t child = 2 * root + 1;
+        size_t sw = root;
+        if (cmp_entry(v[sw], v[child]) < 0)
+            sw = child;
+        if (child + 1 <= end && cmp_entry(v[sw], v[child + 1]) < 0)
+            sw = child + 1;
+        if (sw == root)
+            return;
+        std::swap(v[root], v[sw]);
+        root = sw;
+        }
+    }
+
+static void sort_index(std::vector<pgsd_index_entry>& v)
+    {
+    if (v.size() <= 1)
+        return;
+    for (ssize_t start = (ssize_t)((v.size() - 2) / 2); start >= 0; start--)
+        sift_down(v, (size_t)start, v.size() - 1);
+    for (size_t end = v.size() - 1; end > 0;)
+        {
+        std::swap(v[end], v[0]);
+        end--;
+        sift_down(v, 0, end);
+        }
+    }
+
+struct Impl
+    {
+    pgsd_comm comm;
+    int rank = 0, P = 1;
+    int fd = -1;
+    pgsd_header header;
+    std::vector<pgsd_index_entry> file_index; // .size() == entries allocated on disk
+    size_t file_index_size = 0;               // entries in use
+    std::vector<pgsd_index_entry> frame_index, buffer_index;
+    ByteBuf file_names, frame_names;
+    size_t file_n_names = 0, frame_n_names = 0;
+    std::unordered_map<std::string, uint16_t> name_map;
+    std::vector<char> write_buffer;   // this rank's buffered small-chunk bytes
+    std::vector<uint64_t> wb_sizes;   // every rank's write_buffer size (replicated)
+    uint64_t cur_frame = 0;
+    long long file_size = 0;
+    pgsd_open_flag flags = PGSD_OPEN_READWRITE;
+    uint64_t pending = 0;
+    uint64_t maxbuf = DEFAULT_MAXIMUM_WRITE_BUFFER_SIZE;
+    uint64_t idxbuf = DEFAULT_INDEX_ENTRIES_TO_BUFFER;
+    bool dirty_data = false; // a direct/device chunk was written since the last flush
+    WriterPool* pool = nullptr;
+    DevicePipeline* dev = nullptr;
+    pgsd_device_config devcfg;
+    bool devcfg_set = false;
+
+    bool v1() const
+        {
+        return header.pgsd_version < make_version(2, 0);
+        }
+
+    WriterPool* get_pool()
+        {
+        if (!pool)
+            {
+            unsigned n = 8;
+            if (const char* e = getenv("PGSD_WRITERS"))
+                n = (unsigned)atoi(e);
+            if (devcfg_set && devcfg.n_writers)
+                n = devcfg.n_writers;
+            pool = writer_pool_create(n);
+            }
+        return pool;
+        }
+
+    int allgather_u64(uint64_t v, std::vector<uint64_t>& out)
+        {
+        out.assign((size_t)P, 0);
+        if (P == 1)
+            {
+            out[0] = v;
+            return PGSD_SUCCESS;
+            }
+        if (comm.allgather(comm.ctx, &v, out.data(), sizeof(uint64_t)) != 0)
+            {
+            set_last_error("communicator allgather failed");
+            return PGSD_ERROR_COMM;
+            }
+        return PGSD_SUCCESS;
+        }
+    };
+
+static Impl* impl_of(pgsd_handle* h)
+    {
+    return h ? (Impl*)h->impl : nullptr;
+    }
+
+// refresh the caller-visible mirror (the reference exposes its state directly, pgsd.h:297-353)
+static void publish(pgsd_handle* h, Impl* s)
+    {
+    h->fd = s->fd;
+    h->header = s->header;
+    h->file_index.data = s->file_index.data();
+    h->file_index.size = s->file_index_size;
+    h->file_index.reserved = s->file_index.size();
+    h->file_names.data.data = s->file_names.d.data();
+    h->file_names.data.size = s->file_names.size;
+    h->file_names.data.reserved = s->file_names.reserved();
+    h->file_names.n_names = s->file_n_names;
+    h->cur_frame = s->cur_frame;
+    h->file_size = s->file_size;
+    h->open_flags = s->flags;
+    h->pending_index_entries = s->pending;
+    h->maximum_write_buffer_size = s->maxbuf;
+    h->index_entries_to_buffer = s->idxbuf;
+    h->rank = s->rank;
+    h->nprocs = s->P;
+    }
+
+// every rank learns the first non-zero status (rank order) and its errno
+static int agree_status(Impl* s, int local_rc)
+    {
+    if (s->P == 1)
+        return local_rc;
+    int32_t mine[2] = {local_rc, local_rc ? errno : 0};
+    std::vector<int32_t> all((size_t)s->P * 2);
+    if (s->comm.allgather(s->comm.ctx, mine, all.data(), sizeof(mine)) != 0)
+        {
+        set_last_error("communicator allgather failed");
+        return PGSD_ERROR_COMM;
+        }
+    for (int r = 0; r < s->P; r++)
+        if (all[(size_t)r * 2] != 0)
+            {
+            if (local_rc == 0)
+                errno = all[(size_t)r * 2 + 1];
+            return all[(size_t)r * 2];
+            }
+    return PGSD_SUCCESS;
+    }
+
+// fresh-file skeleton, pgsd.c:1414-1474 (rank 0 only)
+static int initialize_file(int fd, const char* application, const char* schema, uint32_t schema_version)
+    {
+    if (ftruncate(fd, 0) != 0)
+        return PGSD_ERROR_IO;
+    std::vector<char> img(sizeof(pgsd_header) + INITIAL_INDEX_SIZE * sizeof(pgsd_index_entry)
+                              + INITIAL_NAME_BUFFER_SIZE,
+                          0);
+    pgsd_header* hd = (pgsd_header*)img.data();
+    hd->magic = MAGIC_ID;
+    hd->pgsd_version = make_version(CURRENT_FILE_VERSION, 0);
+    strncpy(hd->application, application, sizeof(hd->application) - 1);
+    strncpy(hd->schema, schema, sizeof(hd->schema) - 1);
+    hd->schema_version = schema_version;
+    hd->index_location = sizeof(pgsd_header);
+    hd->index_allocated_entries = INITIAL_INDEX_SIZE;
+    hd->namelist_location = hd->index_location + sizeof(pgsd_index_entry) * hd->index_allocated_entries;
+    hd->namelist_allocated_entries = INITIAL_NAME_BUFFER_SIZE / PGSD_NAME_SIZE;
+    return pwrite_full(fd, img.data(), img.size(), 0) == 0 ? PGSD_SUCCESS : PGSD_ERROR_IO;
+    }
+
+// number of used entries of an index block = first entry with location == 0
+// (binary search of pgsd.c:661-704; validity checks are applied by the caller on open)
+static size_t used_entries(const std::vector<pgsd_index_entry>& v)
+    {
+    if (v.empty() || v[0].location == 0)
+        return 0;
+    size_t L = 0, R = v.size();
+    do
+        {
+        size_t m = (L + R) / 2;
+        if (v[m].location != 0)
+            L = m;
+        else
+            R = m;
+        } while ((R - L) > 1);
+    return R;
+    }
+
+static bool entry_valid(const Impl* s, const pgsd_index_entry& e)
+    {
+    // pgsd.c:414-450
+    if (sizeof_type(e.type) == 0)
+        return false;
+    size_t size = e.N * e.M * sizeof_type(e.type);
+    if ((uint64_t)(e.location + size) > (uint64_t)s->file_size)
+        return false;
+    if (e.frame >= s->header.index_allocated_entries)
+        return false;
+    if (e.id >= (s->file_n_names + s->frame_n_names))
+        return false;
+    if (e.flags != 0)
+        return false;
+    return true;
+    }
+
+// pgsd.c:1484-1703, executed by every rank (the reference parses names/index on rank 0 only)
+static int initialize_handle(Impl* s)
+    {
+    memset(&s->header, 0, sizeof(s->header));
+    pread_some(s->fd, &s->header, sizeof(s->header), 0);
+    if (s->header.magic != MAGIC_ID)
+        return PGSD_ERROR_NOT_A_PGSD_FILE;
+    if (s->header.pgsd_version < make_version(1, 0) && s->header.pgsd_version != make_version(0, 3))
+        return PGSD_ERROR_INVALID_PGSD_FILE_VERSION;
+    if (s->header.pgsd_version >= make_version(3, 0))
+        return PGSD_ERROR_INVALID_PGSD_FILE_VERSION;
+
+    struct stat st;
+    if (fstat(s->fd, &st) != 0)
+        return PGSD_ERROR_IO;
+    s->file_size = (long long)st.st_size;
+
+    if (s->header.namelist_location + (PGSD_NAME_SIZE * s->header.namelist_allocated_entries)
+        > (uint64_t)s->file_size)
+        return PGSD_ERROR_FILE_CORRUPT;
+
+    // name list
+    size_t namelist_n_bytes = PGSD_NAME_SIZE * s->header.namelist_allocated_entries;
+    if (namelist_n_bytes == 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    s->file_names.allocate(namelist_n_bytes);
+    pread_some(s->fd, s->file_names.d.data(), namelist_n_bytes, (long long)s->header.namelist_location);
+    if (s->file_names.d[namelist_n_bytes - 1] != 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    size_t name_start = 0;
+    s->file_n_names = 0;
+    s->name_map.clear();
+    while (name_start < namelist_n_bytes)
+        {
+        const char* name = s->file_names.d.data() + name_start;
+        if (name[0] == 0)
+            break;
+        // first occurrence wins, like the chained hash map's lookup order (pgsd.c:374-405)
+        s->name_map.emplace(std::string(name), (uint16_t)s->file_n_names);
+        s->file_n_names++;
+        if (s->v1())
+            name_start += PGSD_NAME_SIZE;
+        else
+            name_start += strnlen(name, namelist_n_bytes - name_start) + 1;
+        }
+    s->file_names.size = name_start;
+
+    // index block, pgsd.c:602-707
+    if (s->header.index_location + sizeof(pgsd_index_entry) * s->header.index_allocated_entries
+        > (uint64_t)s->file_size)
+        return PGSD_ERROR_FILE_CORRUPT;
+    if (s->header.index_allocated_entries == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    s->file_index.assign(s->header.index_allocated_entries, pgsd_index_entry());
+    memset(s->file_index.data(), 0, s->file_index.size() * sizeof(pgsd_index_entry));
+    pread_some(s->fd, s->file_index.data(), sizeof(pgsd_index_entry) * s->file_index.size(),
+               (long long)s->header.index_location);
+    if (s->file_index[0].location != 0 && !entry_valid(s, s->file_index[0]))
+        return PGSD_ERROR_FILE_CORRUPT;
+    if (s->file_index[0].location == 0)
+        s->file_index_size = 0;
+    else
+        {
+        size_t L = 0, R = s->file_index.size();
+        do
+            {
+            size_t m = (L + R) / 2;
+            if (s->file_index[m].location != 0
+                && (!entry_valid(s, s->file_index[m]) || s->file_index[m].frame < s->file_index[L].frame))
+                return PGSD_ERROR_FILE_CORRUPT;
+            if (s->file_index[m].location != 0)
+                L = m;
+            else
+                R = m;
+            } while ((R - L) > 1);
+        s->file_index_size = R;
+        }
+
+    s->cur_frame = s->file_index_size == 0 ? 0 : s->file_index[s->file_index_size - 1].frame + 1;
+
+    s->frame_index.clear();
+    s->buffer_index.clear();
+    s->write_buffer.clear();
+    s->wb_sizes.assign((size_t)s->P, 0);
+    s->frame_n_names = 0;
+    if (s->flags != PGSD_OPEN_READONLY)
+        s->frame_names.allocate(INITIAL_FRAME_NAMES_SIZE);
+    s->pending = 0;
+    s->maxbuf = DEFAULT_MAXIMUM_WRITE_BUFFER_SIZE;
+    s->idxbuf = DEFAULT_INDEX_ENTRIES_TO_BUFFER;
+    return PGSD_SUCCESS;
+    }
+
+static void destroy_impl(Impl* s)
+    {
+    if (!s)
+        return;
+    if (s->dev)
+        device_pipeline_destroy(s->dev);
+    if (s->pool)
+        writer_pool_destroy(s->pool);
+    if (s->fd >= 0)
+        close(s->fd);
+    delete s;
+    }
+
+static Impl* new_impl()
+    {
+    Impl* s = new Impl;
+    s->comm = default_comm();
+    s->rank = s->comm.rank;
+    s->P = s->comm.size;
+    memset(&s->header, 0, sizeof(s->header));
+    memset(&s->devcfg, 0, sizeof(s->devcfg));
+    return s;
+    }
+
+// pgsd_flush_name_buffer, pgsd.c:1216-1319
+static int flush_name_buffer(Impl* s)
+    {
+    if (s->frame_n_names == 0)
+        return PGSD_SUCCESS;
+    if (s->frame_names.size == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    size_t old_reserved = s->file_names.reserved();
+    size_t old_size = s->file_names.size;
+    s->file_names.append(s->frame_names.d.data(), s->frame_names.size);
+    s->file_n_names += s->frame_n_names;
+    s->frame_n_names = 0;
+    s->frame_names.size = 0;
+    std::fill(s->frame_names.d.begin(), s->frame_names.d.end(), 0);
+    if (s->file_names.reserved() % PGSD_NAME_SIZE != 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+
+    int rc = PGSD_SUCCESS;
+    if (s->file_names.reserved() > old_reserved)
+        {
+        // the list outgrew its block: append the whole list at the end of the file and
+        // point the header at it, pgsd.c:1284-1300
+        long long offset = s->file_size;
+        s->file_size += (long long)s->file_names.reserved();
+        s->header.namelist_location = (uint64_t)offset;
+        s->header.namelist_allocated_entries = s->file_names.reserved() / PGSD_NAME_SIZE;
+        if (s->rank == 0)
+            {
+            if (pwrite_full(s->fd, s->file_names.d.data(), s->file_names.reserved(), offset) != 0
+                || pwrite_full(s->fd, &s->header, sizeof(s->header), 0) != 0)
+                rc = PGSD_ERROR_IO;
+            }
+        }
+    else if (s->rank == 0)
+        {
+        // in place: rewrite [old_size, reserved), pgsd.c:1304-1306
+        if (pwrite_full(s->fd, s->file_names.d.data() + old_size, s->file_names.reserved() - old_size,
+                        (long long)s->header.namelist_location + (long long)old_size)
+            != 0)
+            rc = PGSD_ERROR_IO;
+        }
+    return rc;
+    }
+
+// pgsd_flush_write_buffer, pgsd.c:1108-1201.  The MPI_Allgather of buffer sizes
+// (pgsd.c:1126) is not needed: wb_sizes already holds every rank's size.
+static int flush_write_buffer(Impl* s)
+    {
+    uint64_t total = 0;
+    for (uint64_t b : s->wb_sizes)
+        total += b;
+    if (total == 0 && s->buffer_index.empty())
+        return PGSD_SUCCESS;
+    if (s->wb_sizes[0] > 0 && s->buffer_index.empty())
+        return PGSD_ERROR_INVALID_ARGUMENT; // pgsd.c:1135-1143
+
+    // rank r's copy lands at file_size + sum_{j<r} size_j (pgsd.c:1145-1154).  Every rank
+    // buffered its own copy of the replicated chunks, so a P-rank file holds P copies and
+    // the index points at rank 0's -- kept, because the file must match byte for byte.
+    long long offset_root = s->file_size;
+    long long offset = s->file_size;
+    for (int j = 0; j < s->rank; j++)
+        offset += (long long)s->wb_sizes[(size_t)j];
+    int rc = PGSD_SUCCESS;
+    if (!s->write_buffer.empty())
+        if (pwrite_full(s->fd, s->write_buffer.data(), s->write_buffer.size(), offset) != 0)
+            rc = PGSD_ERROR_IO;
+    s->write_buffer.clear();
+    std::fill(s->wb_sizes.begin(), s->wb_sizes.end(), 0);
+    s->file_size += (long long)total;
+
+    for (const pgsd_index_entry& e : s->buffer_index)
+        {
+        s->frame_index.push_back(e);
+        s->frame_index.back().location += offset_root; // pgsd.c:1191-1192
+        }
+    s->buffer_index.clear();
+    return rc;
+    }
+
+// pgsd_expand_file_index, pgsd.c:965-1091
+static int expand_file_index(Impl* s, size_t size_required, int* local_rc)
+    {
+    size_t size_old = s->header.index_allocated_entries;
+    size_t size_new = size_old * 2;
+    while (size_new <= size_required)
+        size_new *= 2;
+
+    // The new block goes to the TRUE end of the file as rank 0 sees it
+    // (MPI_File_get_size, pgsd.c:1015) once every rank's data is in the file.
+    int brc = comm_barrier(s->comm);
+    if (brc != PGSD_SUCCESS)
+        return brc;
+    uint64_t eof = 0;
+    if (s->rank == 0)
+        {
+        struct stat st;
+        if (fstat(s->fd, &st) != 0)
+            *local_rc = PGSD_ERROR_IO;
+        eof = (uint64_t)st.st_size;
+        }
+    std::vector<uint64_t> all;
+    int rc = s->allgather_u64(eof, all);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    long long new_loc = (long long)all[0];
+    long long old_loc = (long long)s->header.index_location;
+    size_t old_bytes = size_old * sizeof(pgsd_index_entry);
+    size_t new_bytes = size_new * sizeof(pgsd_index_entry);
+
+    if (s->rank == 0)
+        {
+        // copy the old block in pieces, then zero-fill (pgsd.c:1021-1062)
+        size_t piece = INDEX_COPY_ENTRIES * sizeof(pgsd_index_entry);
+        if (piece > old_bytes)
+            piece = old_bytes;
+        std::vector<char> buf(piece);
+        size_t done = 0;
+        while (done < old_bytes)
+            {
+            size_t n = old_bytes - done < piece ? old_bytes - done : piece;
+            pread_some(s->fd, buf.data(), n, old_loc + (long long)done);
+            if (pwrite_full(s->fd, buf.data(), n, new_loc + (long long)done) != 0)
+                *local_rc = PGSD_ERROR_IO;
+            done += n;
+            }
+        std::fill(buf.begin(), buf.end(), 0);
+        while (done < new_bytes)
+            {
+            size_t n = new_bytes - done < piece ? new_bytes - done : piece;
+            if (pwrite_full(s->fd, buf.data(), n, new_loc + (long long)done) != 0)
+                *local_rc = PGSD_ERROR_IO;
+            done += n;
+            }
+        }
+    s->header.index_location = (uint64_t)new_loc;
+    s->file_size = new_loc + (long long)new_bytes;
+    s->header.index_allocated_entries = size_new;
+    if (s->rank == 0)
+        if (pwrite_full(s->fd, &s->header, sizeof(s->header), 0) != 0)
+            *local_rc = PGSD_ERROR_IO;
+
+    // the in-memory mirror is the old block plus zeros; its used size is found the way
+    // pgsd_index_buffer_map finds it after re-reading (pgsd.c:661-704, 1083)
+    pgsd_index_entry zero;
+    memset(&zero, 0, sizeof(zero));
+    s->file_index.resize(size_new, zero);
+    s->file_index_size = used_entries(s->file_index);
+    return PGSD_SUCCESS;
+    }
+
+// pgsd_flush, pgsd.c:1955-2070
+static int do_flush(Impl* s)
+    {
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+
+    // Replicated state tells every rank alike whether there is anything to do.
+    bool work = s->frame_n_names > 0 || !s->buffer_index.empty() || !s->frame_index.empty()
+                || s->dirty_data;
+    for (uint64_t b : s->wb_sizes)
+        work = work || b > 0;
+    if (!work)
+        return PGSD_SUCCESS;
+
+    int local_rc = PGSD_SUCCESS;
+    // device chunks of this rank must be in the file before the frame is sealed
+    if (s->dev)
+        {
+        std::string err;
+        int drc = device_pipeline_drain(s->dev, &err);
+        if (drc != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            local_rc = drc;
+            }
+        }
+    int rc = flush_name_buffer(s);
+    if (rc != PGSD_SUCCESS && local_rc == PGSD_SUCCESS)
+        local_rc = rc;
+    rc = flush_write_buffer(s);
+    if (rc != PGSD_SUCCESS && local_rc == PGSD_SUCCESS)
+        local_rc = rc;
+
+    if (s->pending > s->frame_index.size())
+        {
+        if (local_rc == PGSD_SUCCESS)
+            local_rc = PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    else
+        {
+        uint64_t to_write = s->frame_index.size() - s->pending;
+        if (to_write > 0)
+            {
+            if ((s->file_index_size + to_write) > s->file_index.size())
+                {
+                int erc = expand_file_index(s, s->file_index_size + to_write, &local_rc);
+                if (erc != PGSD_SUCCESS)
+                    return erc; // communicator failure: nothing sane left to agree on
+                }
+            sort_index(s->frame_index);
+            long long write_pos = (long long)s->header.index_location
+                                  + (long long)(sizeof(pgsd_index_entry) * s->file_index_size);
+            // all frame_index entries are written, the pending ones of an open frame
+            // included (pgsd.c:2032); they are overwritten by the next flush
+            if (s->rank == 0)
+                if (pwrite_full(s->fd, s->frame_index.data(),
+                                sizeof(pgsd_index_entry) * s->frame_index.size(), write_pos)
+                    != 0)
+                    local_rc = PGSD_ERROR_IO;
+            size_t room = s->file_index.size() - s->file_index_size;
+            size_t ncopy = s->frame_index.size() < room ? s->frame_index.size() : room;
+            memcpy(s->file_index.data() + s->file_index_size, s->frame_index.data(),
+                   sizeof(pgsd_index_entry) * ncopy);
+            s->file_index_size += to_write;
+
+            // keep the entries of the open frame: every kept slot receives the first
+            // pending entry (the reference copies without "+ i", pgsd.c:2049-2057)
+            if (s->pending > 0)
+                {
+                pgsd_index_entry first = s->frame_index[s->frame_index.size() - s->pending];
+                for (uint64_t i = 0; i < s->pending; i++)
+                    s->frame_index[i] = first;
+                }
+            s->frame_index.resize(s->pending);
+            }
+        }
+    s->dirty_data = false;
+    return agree_status(s, local_rc);
+    }
+
+static int do_end_frame(Impl* s)
+    {
+    // pgsd.c:1916-1953
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    s->cur_frame++;
+    s->pending = 0;
+    if (!s->frame_index.empty() || s->buffer_index.size() > s->idxbuf)
+        return do_flush(s);
+    return PGSD_SUCCESS;
+    }
+
+// name -> id; new names get the next id in first-seen order (pgsd.c:2111-2133, 1340-1404)
+static int name_to_id(Impl* s, const char* name, uint16_t* id)
+    {
+    auto it = s->name_map.find(name);
+    if (it != s->name_map.end())
+        {
+        *id = it->second;
+        return PGSD_SUCCESS;
+        }
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    if (s->file_n_names + s->frame_n_names == UINT16_MAX)
+        return PGSD_ERROR_NAMELIST_FULL;
+    *id = (uint16_t)(s->file_n_names + s->frame_n_names);
+    if (s->v1())
+        {
+        char name_v1[PGSD_NAME_SIZE];
+        strncpy(name_v1, name, PGSD_NAME_SIZE - 1);
+        name_v1[PGSD_NAME_SIZE - 1] = 0;
+        s->frame_names.append(name_v1, PGSD_NAME_SIZE);
+        s->name_map.emplace(std::string(name_v1), *id);
+        }
+    else
+        {
+        s->frame_names.append(name, strlen(name) + 1);
+        s->name_map.emplace(std::string(name), *id);
+        }
+    s->frame_n_names++;
+    return PGSD_SUCCESS;
+    }
+
+// Where a chunk's bytes go, decided exactly as pgsd_write_chunk decides (pgsd.c:2143-2256).
+struct Placement
+    {
+    bool buffered;         // append to this rank's small-chunk buffer
+    bool write;            // this rank writes bytes in the direct path
+    long long file_offset; // direct path: where this rank's rows start
+    size_t size;           // bytes of this rank
+    };
+
+static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uint32_t M,
+                       uint64_t N_global, uint32_t M_global, uint64_t offset, uint64_t global_size,
+                       bool all, uint8_t flags, bool have_data, Placement* pl)
+    {
+    if (N > 0 && !have_data)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (M == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    if (flags != 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!name)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+
+    uint16_t id;
+    int rc = name_to_id(s, name, &id);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+
+    pgsd_index_entry entry;
+    memset(&entry, 0, sizeof(entry));
+    entry.frame = s->cur_frame;
+    entry.id = id;
+    entry.type = (uint8_t)type;
+    entry.N = N_global;
+    entry.M = M_global;
+
+    const size_t sz = sizeof_type(type);
+    const size_t size = (size_t)(N * M * sz);
+    pl->size = size;
+
+    // max and sum of `size` over the ranks (MPI_Allreduce MAX pgsd.c:2157, SUM pgsd.c:2242)
+    uint64_t maxsize = size, sumsize = size;
+    std::vector<uint64_t> sizes;
+    if (s->P > 1)
+        {
+        if (all && global_size != 0)
+            {
+            // per-particle chunk: the caller already knows the global element count
+            // (fl.pyx:649, benchmark-write.cc:99), no exchange needed
+            sumsize = global_size * sz;
+            maxsize = sumsize; // only compared when !all
+            }
+        else
+            {
+            rc = s->allgather_u64(size, sizes);
+            if (rc != PGSD_SUCCESS)
+                return rc;
+            maxsize = 0;
+            sumsize = 0;
+            for (uint64_t v : sizes)
+                {
+                if (v > maxsize)
+                    maxsize = v;
+                sumsize += v;
+                }
+            }
+        }
+    else
+        sizes.assign(1, size);
+
+    if (maxsize < s->maxbuf && !all)
+        {
+        // BUFFERED, pgsd.c:2160-2202.  Flush first when the chunk does not fit any more.
+        bool need_flush = false;
+        for (int r = 0; r < s->P; r++)
+            if (sizes[(size_t)r] > (s->maxbuf - s->wb_sizes[(size_t)r]))
+                need_flush = true;
+        if (need_flush)
+            flush_write_buffer(s);
+        entry.location = (int64_t)s->wb_sizes[0]; // offset inside rank 0's buffer
+        s->buffer_index.push_back(entry);
+        for (int r = 0; r < s->P; r++)
+            s->wb_sizes[(size_t)r] += sizes[(size_t)r];
+        pl->buffered = true;
+        pl->write = false;
+        pl->file_offset = -1;
+        }
+    else
+        {
+        // DIRECT, pgsd.c:2203-2250
+        entry.location = s->file_size;
+        s->frame_index.push_back(entry);
+        pl->buffered = false;
+        pl->write = all || s->rank == 0;
+        pl->file_offset = s->file_size + (long long)(offset * sz);
+        // file_size advances by the sum over all ranks even when only rank 0 wrote
+        // (all == false): the hole is part of the reference's layout (pgsd.c:2240-2249)
+        s->file_size += (long long)sumsize;
+        s->dirty_data = true;
+        }
+    s->pending++;
+    return PGSD_SUCCESS;
+    }
+
+static int ensure_device(Impl* s)
+    {
+    if (s->dev)
+        return PGSD_SUCCESS;
+    pgsd_device_config cfg = s->devcfg;
+    if (!s->devcfg_set)
+        {
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.device = -1;
+        }
+    std::string err;
+    s->dev = device_pipeline_create(cfg, s->fd, &err);
+    if (!s->dev)
+        {
+        set_last_error(err);
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
+    } // namespace pgsd_amd
+
+using namespace pgsd_amd;
+
+// ============================================================================ C ABI
+
+extern "C" uint32_t pgsd_make_version(unsigned int major, unsigned int minor)
+    {
+    return make_version(major, minor);
+    }
+
+extern "C" size_t pgsd_sizeof_type(enum pgsd_type type)
+    {
+    return sizeof_type((uint32_t)type);
+    }
+
+extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fname, const char* application,
+                                    const char* schema, uint32_t schema_version,
+                                    enum pgsd_open_flag flags, int exclusive_create)
+    {
+    // pgsd.c:1710-1773
+    if (!handle || !fname || !application || !schema)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    memset(handle, 0, sizeof(*handle));
+    handle->fd = -1;
+    if (flags == PGSD_OPEN_READONLY)
+        return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    Impl* s = new_impl();
+    s->flags = flags;
+
+    // rank 0 creates and lays out the file, then everybody opens it
+    int rc = PGSD_SUCCESS;
+    if (s->rank == 0)
+        {
+        s->fd = open(fname, O_RDWR | O_CREAT | (exclusive_create ? O_EXCL : 0), 0644);
+        if (s->fd < 0)
+            rc = PGSD_ERROR_IO;
+        else
+            rc = initialize_file(s->fd, application, schema, schema_version);
+        }
+    rc = agree_status(s, rc);
+    if (rc == PGSD_SUCCESS && s->rank != 0)
+        {
+        s->fd = open(fname, O_RDWR);
+        if (s->fd < 0)
+            rc = PGSD_ERROR_IO;
+        }
+    if (rc == PGSD_SUCCESS)
+        rc = initialize_handle(s);
+    if (s->P > 1)
+        {
+        // agree after the local open/parse as well (bcast_retval, pgsd.c:1763)
+        rc = agree_status(s, rc);
+        }
+    if (rc != PGSD_SUCCESS)
+        {
+        int saved = errno;
+        destroy_impl(s);
+        errno = saved;
+        return rc;
+        }
+    handle->impl = s;
+    publish(handle, s);
+    return PGSD_SUCCESS;
+    }
+
+extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags)
+    {
+    // pgsd.c:1775-1812
+    if (!handle || !fname)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    memset(handle, 0, sizeof(*handle));
+    handle->fd = -1;
+    Impl* s = new_impl();
+    s->flags = flags;
+    int rc = PGSD_SUCCESS;
+    s->fd = open(fname, flags == PGSD_OPEN_READONLY ? O_RDONLY : O_RDWR);
+    if (s->fd < 0)
+        rc = PGSD_ERROR_IO;
+    else
+        rc = initialize_handle(s);
+    rc = agree_status(s, rc);
+    if (rc != PGSD_SUCCESS)
+        {
+        int saved = errno;
+        destroy_impl(s);
+        errno = saved;
+        return rc;
+        }
+    handle->impl = s;
+    publish(handle, s);
+    return PGSD_SUCCESS;
+    }
+
+extern "C" int pgsd_close(struct pgsd_handle* handle)
+    {
+    // pgsd.c:1814-1914
+    if (!handle)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = PGSD_SUCCESS;
+    if (s->flags != PGSD_OPEN_READONLY)
+        {
+        rc = do_flush(s);
+        if (rc != PGSD_SUCCESS)
+            {
+            publish(handle, s);
+            return rc;
+            }
+        }
+    int fd = s->fd;
+    s->fd = -1;
+    destroy_impl(s);
+    handle->impl = NULL;
+    handle->file_index.data = NULL;
+    handle->file_names.data.data = NULL;
+    handle->fd = -1;
+    if (close(fd) != 0)
+        return PGSD_ERROR_IO;
+    return PGSD_SUCCESS;
+    }
+
+extern "C" int pgsd_end_frame(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = do_end_frame(s);
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_flush(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = do_flush(s);
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, enum pgsd_type type, uint64_t N,
+                                uint32_t M, uint64_t N_global, uint32_t M_global, uint64_t offset,
+                                uint64_t global_size, bool all, uint8_t flags, const void* data)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    Placement pl;
+    int rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, global_size, all,
+                         flags, data != NULL, &pl);
+    if (rc == PGSD_SUCCESS)
+        {
+        if (pl.buffered)
+            {
+            if (pl.size > 0)
+                s->write_buffer.insert(s->write_buffer.end(), (const char*)data,
+                                       (const char*)data + pl.size);
+            }
+        else if (pl.write && pl.size > 0)
+            {
+            // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
+            int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset);
+            if (e != 0)
+                {
+                errno = -e;
+                rc = PGSD_ERROR_IO;
+                }
+            }
+        }
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" uint64_t pgsd_get_nframes(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    return s ? s->cur_frame : 0;
+    }
+
+extern "C" uint64_t pgsd_get_nnames(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    return s ? s->file_n_names : 0;
+    }
+
+extern "C" const struct pgsd_index_entry* pgsd_find_chunk(struct pgsd_handle* handle, uint64_t frame,
+                                                          const char* name)
+    {
+    // pgsd.c:2295-2434; valid on every rank because the index is replicated
+    Impl* s = impl_of(handle);
+    if (!s || !name)
+        return NULL;
+    if (frame >= s->cur_frame)
+        return NULL;
+    if (s->flags != PGSD_OPEN_READONLY)
+        {
+        int rc = do_flush(s);
+        publish(handle, s);
+        if (rc != PGSD_SUCCESS)
+            return NULL;
+        }
+    auto it = s->name_map.find(name);
+    if (it == s->name_map.end())
+        return NULL;
+    uint16_t match_id = it->second;
+
+    if (!s->v1())
+        {
+        ssize_t L = 0, R = (ssize_t)s->file_index_size - 1;
+        pgsd_index_entry T;
+        memset(&T, 0, sizeof(T));
+        T.frame = frame;
+        T.id = match_id;
+        while (L <= R)
+            {
+            size_t m = (size_t)((L + R) / 2);
+            int c = cmp_entry(s->file_index[m], T);
+            if (c == -1)
+                L = (ssize_t)m + 1;
+            else if (c == 1)
+                R = (ssize_t)m - 1;
+            else
+                return &s->file_index[m];
+            }
+        return NULL;
+        }
+    // v1 files: the index is only ordered by frame (pgsd.c:2380-2430)
+    if (s->file_index_size == 0)
+        return NULL;
+    size_t L = 0, R = s->file_index_size;
+    do
+        {
+        size_t m = (L + R) / 2;
+        if (frame < s->file_index[m].frame)
+            R = m;
+        else
+            L = m;
+        } while ((R - L) > 1);
+    for (int64_t cur = (int64_t)L; cur >= 0 && s->file_index[(size_t)cur].frame == frame; cur--)
+        if (s->file_index[(size_t)cur].id == match_id)
+            return &s->file_index[(size_t)cur];
+    return NULL;
+    }
+
+extern "C" int pgsd_read_chunk(struct pgsd_handle* handle, void* data, const struct pgsd_index_entry* chunk,
+                               uint64_t N, uint32_t M, uint32_t offset, bool all)
+    {
+    // pgsd.c:2436-2537
+    Impl* s = impl_of(handle);
+    if (!s || !data || !chunk)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    // copy first: a flush may move the index storage the entry points into
+    pgsd_index_entry c = *chunk;
+    if (s->flags != PGSD_OPEN_READONLY)
+        {
+        int rc = do_flush(s);
+        publish(handle, s);
+        if (rc != PGSD_SUCCESS)
+            return rc;
+        }
+    size_t sz = sizeof_type(c.type);
+    uint64_t stride = 0;
+    size_t size;
+    uint64_t off_elems = (uint64_t)offset * M;
+    if (!all)
+        size = c.N * c.M * sz;
+    else
+        {
+        size = N * M * sz;
+        stride = off_elems * sz;
+        }
+    if (size == 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    if (c.location == 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    if ((uint64_t)(c.location + size + stride) > (uint64_t)s->file_size)
+        return PGSD_ERROR_FILE_CORRUPT;
+    pread_some(s->fd, data, size, c.location + (long long)stride);
+    return PGSD_SUCCESS;
+    }
+
+extern "C" const char* pgsd_find_matching_chunk_name(struct pgsd_handle* handle, const char* match,
+                                                     const char* prev)
+    {
+    // pgsd.c:2557-2641
+    Impl* s = impl_of(handle);
+    if (!s || !match)
+        return NULL;
+    if (s->file_n_names == 0)
+        return NULL; // checked before the flush, like pgsd.c:2573-2584
+    if (s->flags != PGSD_OPEN_READONLY)
+        {
+        // `prev` points into the name storage, which a flush may reallocate: carry it over
+        size_t prev_off = 0;
+        bool have_prev = prev != NULL;
+        if (have_prev)
+            {
+            if (prev < s->file_names.d.data() || prev >= s->file_names.d.data() + s->file_names.reserved())
+                return NULL;
+            prev_off = (size_t)(prev - s->file_names.d.data());
+            }
+        int rc = do_flush(s);
+        publish(handle, s);
+        if (rc != PGSD_SUCCESS)
+            return NULL;
+        if (have_prev)
+            prev = s->file_names.d.data() + prev_off;
+        }
+    if (s->file_n_names == 0)
+        return NULL;
+    const char* base = s->file_names.d.data();
+    const char* end = base + s->file_names.reserved();
+    if (end[-1] != 0)
+        return NULL;
+    const char* p;
+    if (!prev)
+        p = base;
+    else
+        {
+        if (prev < base || prev >= end)
+            return NULL;
+        p = s->v1() ? prev + PGSD_NAME_SIZE : prev + strlen(prev) + 1;
+        }
+    size_t ml = strlen(match);
+    while (p < end)
+        {
+        if (p[0] != 0 && 0 == strncmp(match, p, ml))
+            return p;
+        p += s->v1() ? (size_t)PGSD_NAME_SIZE : strlen(p) + 1;
+        }
+    return NULL;
+    }
+
+extern "C" uint64_t pgsd_get_maximum_write_buffer_size(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    return s ? s->maxbuf : 0;
+    }
+
+extern "C" int pgsd_set_maximum_write_buffer_size(struct pgsd_handle* handle, uint64_t size)
+    {
+    Impl* s = impl_of(handle);
+    if (!s || size == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    s->maxbuf = size;
+    publish(handle, s);
+    return PGSD_SUCCESS;
+    }
+
+extern "C" uint64_t pgsd_get_index_entries_to_buffer(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    return s ? s->idxbuf : 0;
+    }
+
+extern "C" int pgsd_set_index_entries_to_buffer(struct pgsd_handle* handle, uint64_t number)
+    {
+    Impl* s = impl_of(handle);
+    if (!s || number == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    s->idxbuf = number;
+    publish(handle, s);
+    return PGSD_SUCCESS;
+    }
+
+// ---------------------------------------------------------------------------- device path
+
+extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg)
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !cfg)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (s->dev)
+        {
+        std::string err;
+        int rc = device_pipeline_drain(s->dev, &err);
+        if (rc != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            return rc;
+            }
+        device_pipeline_destroy(s->dev);
+        s->dev = nullptr;
+        }
+    s->devcfg = *cfg;
+    s->devcfg_set = true;
+    return ensure_device(s);
+    }
+
+static int check_field(const pgsd_field_desc* f, uint32_t dst_type, uint32_t M)
+    {
+    if (!f || !f->src)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    size_t ssz = sizeof_type(f->src_type), dsz = sizeof_type(dst_type);
+    if (ssz == 0 || dsz == 0 || M == 0 || f->src_col0 + M > f->src_stride)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    bool s_int = f->src_type <= PGSD_TYPE_INT64, d_int = dst_type <= PGSD_TYPE_INT64;
+    if (f->bitcast)
+        return dsz <= ssz ? PGSD_SUCCESS : PGSD_ERROR_INVALID_ARGUMENT;
+    if (!s_int && d_int)
+        return PGSD_ERROR_INVALID_ARGUMENT; // float -> integer is not offered
+    if (s_int && !d_int && ssz == 8)
+        return PGSD_ERROR_INVALID_ARGUMENT; // 64-bit integer -> float is not offered
+    return PGSD_SUCCESS;
+    }
+
+extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* name, enum pgsd_type type,
+                                       uint64_t N, uint32_t M, uint64_t N_global, uint32_t M_global,
+                                       uint64_t offset, uint64_t global_size, bool all, uint8_t flags,
+                                       const struct pgsd_field_desc* src)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (N > 0)
+        {
+        int rc = check_field(src, (uint32_t)type, M);
+        if (rc != PGSD_SUCCESS)
+            return rc;
+        }
+    int rc = ensure_device(s);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    Placement pl;
+    rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, global_size, all, flags,
+                     N == 0 || (src && src->src), &pl);
+    if (rc == PGSD_SUCCESS && pl.size > 0 && (pl.buffered || pl.write))
+        {
+        std::vector<DeviceChunk> chunks(1);
+        DeviceChunk& c = chunks[0];
+        memset(&c, 0, sizeof(c));
+        c.job.dst_type = (uint32_t)type;
+        c.job.M = M;
+        c.job.src = *src;
+        c.N = N;
+        std::vector<char> tmp;
+        if (pl.buffered)
+            {
+            tmp.resize(pl.size);
+            c.file_offset = -1;
+            c.host_dst = tmp.data();
+            }
+        else
+            c.file_offset = pl.file_offset;
+        std::string err;
+        rc = device_pipeline_submit(s->dev, chunks, N, &err);
+        if (rc != PGSD_SUCCESS)
+            set_last_error(err);
+        else if (pl.buffered)
+            s->write_buffer.insert(s->write_buffer.end(), tmp.begin(), tmp.end());
+        }
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_chunks,
+                                        const struct pgsd_chunk_req* reqs, uint64_t N, uint64_t N_global,
+                                        uint64_t offset_rows)
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !reqs || n_chunks == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < n_chunks; i++)
+        {
+        if (!reqs[i].name)
+            return PGSD_ERROR_INVALID_ARGUMENT;
+        if (N > 0)
+            {
+            int rc = check_field(&reqs[i].src, reqs[i].type, reqs[i].M);
+            if (rc != PGSD_SUCCESS)
+                return rc;
+            }
+        }
+    int rc = ensure_device(s);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    std::vector<DeviceChunk> chunks;
+    for (uint32_t i = 0; i < n_chunks && rc == PGSD_SUCCESS; i++)
+        {
+        const pgsd_chunk_req& q = reqs[i];
+        Placement pl;
+        rc = place_chunk(s, q.name, q.type, N, q.M, N_global, q.M, offset_rows * q.M,
+                         N_global * (uint64_t)q.M, true, 0, true, &pl);
+        if (rc == PGSD_SUCCESS && pl.size > 0)
+            {
+            DeviceChunk c;
+            memset(&c, 0, sizeof(c));
+            c.job.dst_type = q.type;
+            c.job.M = q.M;
+            c.job.src = q.src;
+            c.N = N;
+            c.file_offset = pl.file_offset;
+            chunks.push_back(c);
+            }
+        }
+    if (rc == PGSD_SUCCESS && !chunks.empty())
+        {
+        std::string err;
+        rc = device_pipeline_submit(s->dev, chunks, N, &err);
+        if (rc != PGSD_SUCCESS)
+            set_last_error(err);
+        }
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_device_wait_packed(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!s->dev)
+        return PGSD_SUCCESS;
+    std::string err;
+    int rc = device_pipeline_wait_packed(s->dev, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
+
+extern "C" int pgsd_device_get_stats(struct pgsd_handle* handle, struct pgsd_device_stats* out, int reset)
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !out)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    if (s->dev)
+        device_pipeline_stats(s->dev, out, reset);
+    return PGSD_SUCCESS;
+    }

@@ -1,0 +1,64 @@
+// pgsd_internal.hpp -- declarations shared by the translation units of libpgsd_amd.so.
+#ifndef PGSD_INTERNAL_HPP
+#define PGSD_INTERNAL_HPP
+
+#include "pgsd.h"
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace pgsd_amd
+    {
+void set_last_error(const std::string& s);
+const char* last_error();
+pgsd_comm default_comm();
+
+inline int comm_barrier(const pgsd_comm& c)
+    {
+    if (c.size == 1)
+        return PGSD_SUCCESS;
+    if (c.barrier)
+        return c.barrier(c.ctx) == 0 ? PGSD_SUCCESS : PGSD_ERROR_COMM;
+    std::vector<char> all((size_t)c.size);
+    char one = 0;
+    return c.allgather(c.ctx, &one, all.data(), 1) == 0 ? PGSD_SUCCESS : PGSD_ERROR_COMM;
+    }
+
+// ---- host IO: a pool of pwrite threads shared by the host and the device path ----
+class WriterPool;
+WriterPool* writer_pool_create(unsigned n_threads);
+void writer_pool_destroy(WriterPool*);
+void writer_pool_submit(WriterPool*, std::function<void()> fn);
+unsigned writer_pool_size(WriterPool*);
+// Write [buf, buf+bytes) at `offset` of fd, split over the pool; blocks until done.
+// Returns 0 or -errno.
+int writer_pool_pwrite_sync(WriterPool*, int fd, const void* buf, size_t bytes, long long offset);
+// plain full-length pwrite / pread loops (0 / -errno; pread leaves a short tail untouched)
+int pwrite_full(int fd, const void* buf, size_t bytes, long long offset);
+void pread_some(int fd, void* buf, size_t bytes, long long offset);
+
+// ---- device pipeline (pgsd_device.cpp); created lazily by the first device call ----
+class DevicePipeline;
+struct DeviceChunk
+    {
+    pgsd_pack_job job;      // dst filled in by the pipeline (device staging)
+    uint64_t N;             // rows of this rank
+    long long file_offset;  // where this rank's rows start in the file; <0: copy into host_dst
+    void* host_dst;         // for small buffered chunks: synchronous copy target
+    };
+DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, std::string* err);
+void device_pipeline_destroy(DevicePipeline*);
+// one fused pack launch for `chunks` (all share N), then async copy + write of each
+int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
+int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
+int device_pipeline_drain(DevicePipeline*, std::string* err);
+void device_pipeline_stats(DevicePipeline*, pgsd_device_stats* out, int reset);
+bool device_pipeline_idle(DevicePipeline*);
+
+size_t sizeof_type(uint32_t type);
+// source bytes that must be read per row for a field (algorithmic, not padded)
+    } // namespace pgsd_amd
+
+#endif

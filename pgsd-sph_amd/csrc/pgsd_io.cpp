@@ -1,0 +1,171 @@
+// pgsd_io.cpp -- positional file IO standing in for the reference's MPI-IO calls
+// (MPI_File_write_at pgsd.c:2229/1154/2032, MPI_File_read_at pgsd.c:651/1559/2534).
+// Each rank writes its own byte range with pwrite at the offset the reference computes;
+// large ranges are split over a small pool of writer threads because a tmpfs / page-cache
+// write is a CPU copy and one core does not saturate host memory bandwidth.
+#include "pgsd_internal.hpp"
+
+#include <cerrno>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
+
+namespace pgsd_amd
+    {
+int pwrite_full(int fd, const void* buf, size_t bytes, long long offset)
+    {
+    const char* p = (const char*)buf;
+    while (bytes > 0)
+        {
+        ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
+        if (w < 0)
+            {
+            if (errno == EINTR)
+                continue;
+            return -errno;
+            }
+        p += w;
+        offset += w;
+        bytes -= (size_t)w;
+        }
+    return 0;
+    }
+
+void pread_some(int fd, void* buf, size_t bytes, long long offset)
+    {
+    char* p = (char*)buf;
+    while (bytes > 0)
+        {
+        ssize_t r = pread(fd, p, bytes, (off_t)offset);
+        if (r <= 0)
+            {
+            if (r < 0 && errno == EINTR)
+                continue;
+            return; // short read: the tail keeps its previous contents
+            }
+        p += r;
+        offset += r;
+        bytes -= (size_t)r;
+        }
+    }
+
+class WriterPool
+    {
+    public:
+    explicit WriterPool(unsigned n) : m_stop(false)
+        {
+        if (n == 0)
+            n = 1;
+        for (unsigned i = 0; i < n; i++)
+            m_threads.emplace_back([this] { run(); });
+        }
+
+    ~WriterPool()
+        {
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_stop = true;
+            }
+        m_cv.notify_all();
+        for (auto& t : m_threads)
+            t.join();
+        }
+
+    void submit(std::function<void()> fn)
+        {
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_jobs.push_back(std::move(fn));
+            }
+        m_cv.notify_one();
+        }
+
+    unsigned size() const
+        {
+        return (unsigned)m_threads.size();
+        }
+
+    private:
+    void run()
+        {
+        for (;;)
+            {
+            std::function<void()> fn;
+                {
+                std::unique_lock<std::mutex> lk(m_mutex);
+                m_cv.wait(lk, [this] { return m_stop || !m_jobs.empty(); });
+                if (m_jobs.empty())
+                    return;
+                fn = std::move(m_jobs.front());
+                m_jobs.pop_front();
+                }
+            fn();
+            }
+        }
+
+    std::vector<std::thread> m_threads;
+    std::deque<std::function<void()>> m_jobs;
+    std::mutex m_mutex;
+    std::condition_variable m_cv;
+    bool m_stop;
+    };
+
+WriterPool* writer_pool_create(unsigned n_threads)
+    {
+    return new WriterPool(n_threads);
+    }
+
+void writer_pool_destroy(WriterPool* p)
+    {
+    delete p;
+    }
+
+void writer_pool_submit(WriterPool* p, std::function<void()> fn)
+    {
+    p->submit(std::move(fn));
+    }
+
+unsigned writer_pool_size(WriterPool* p)
+    {
+    return p->size();
+    }
+
+int writer_pool_pwrite_sync(WriterPool* pool, int fd, const void* buf, size_t bytes, long long offset)
+    {
+    const size_t piece = (size_t)8 << 20;
+    if (!pool || bytes <= piece)
+        return pwrite_full(fd, buf, bytes, offset);
+    struct Latch
+        {
+        std::mutex m;
+        std::condition_variable cv;
+        size_t pending;
+        int err;
+        } latch;
+    size_t n_pieces = (bytes + piece - 1) / piece;
+    latch.pending = n_pieces;
+    latch.err = 0;
+    for (size_t i = 0; i < n_pieces; i++)
+        {
+        size_t off = i * piece;
+        size_t n = bytes - off < piece ? bytes - off : piece;
+        const char* p = (const char*)buf + off;
+        pool->submit(
+            [&latch, fd, p, n, offset, off]
+            {
+                int e = pwrite_full(fd, p, n, offset + (long long)off);
+                std::lock_guard<std::mutex> g(latch.m);
+                if (e != 0 && latch.err == 0)
+                    latch.err = e;
+                if (--latch.pending == 0)
+                    latch.cv.notify_all();
+            });
+        }
+    std::unique_lock<std::mutex> lk(latch.m);
+    latch.cv.wait(lk, [&latch] { return latch.pending == 0; });
+    return latch.err;
+    }
+    } // namespace pgsd_amd

@@ -1,0 +1,674 @@
+// pgsd_pack.hip -- gfx950 (CDNA4 / MI355X) kernels of the snapshot pack path.
+//
+// pack:    chunk[i][c] = convert(src[(order ? order[i] : i) * stride + col0 + c])
+//          for every field of a frame, from HBM-resident particle arrays (HOOMD-style
+//          float4 / double4 / scalar arrays) into dense GSD chunk buffers.
+// select:  stream compaction (filtered snapshots): wave ballot / popcount scans give each
+//          workgroup's count, a one-block scan turns counts into offsets (= per-chunk row
+//          and byte counts), a scatter pass writes the index list.
+//
+// The path is pure data movement, so the design target is the HBM roofline, not MFMA:
+//   * every global access is a 16-byte-per-lane, fully coalesced vector access: a source
+//     tile (TILE rows x row bytes, contiguous in memory) is streamed linearly into LDS,
+//     the re-packed / converted chunk tile is streamed linearly out of it.  The 4->3
+//     component repack, column selection and dtype conversion happen between LDS and
+//     registers, where bandwidth is ~25x the per-CU share of HBM.
+//   * fields that read the same source array (position.xyz and the type id HOOMD keeps
+//     in position.w) form one group: the tile is fetched from HBM once.
+//   * 64-wide wavefronts, 256-thread workgroups, <= 32 KiB LDS per workgroup so that >= 5
+//     workgroups (20 waves) per CU keep ~100 KiB of loads in flight per CU; the grid is
+//     capped at 8 workgroups per CU x 256 CUs and strides over tiles.
+//   * source tiles are read once and chunk tiles written once: non-temporal hints keep
+//     them from displacing each other in L2.
+//
+// No reference counterpart exists (the reference has no device code); the
+// outputs are pinned by oracle_pack_rows() in oracle/pgsd_oracle.c and by the byte layout
+// of chunks in the golden files.
+#include "pgsd_internal.hpp"
+#include "pgsd_pack.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace pgsd_amd
+    {
+#define PACK_THREADS 256
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ device helpers
+
+template<int SSZ> __device__ __forceinline__ uint64_t lds_load(const char* p)
+    {
+    if constexpr (SSZ == 1)
+        return *(const uint8_t*)p;
+    else if constexpr (SSZ == 2)
+        return *(const uint16_t*)p;
+    else if constexpr (SSZ == 4)
+        return *(const uint32_t*)p;
+    else
+        return *(const uint64_t*)p;
+    }
+
+// one element, value semantics selected by `kind` (wave-uniform)
+template<int SSZ, int DSZ> __device__ __forceinline__ uint64_t convert_elem(uint64_t raw, uint32_t kind)
+    {
+    switch (kind)
+        {
+        default:
+        case PACK_BITS: // same width, narrowing, zero-extension, bitcast: low bytes
+            return raw;
+        case PACK_SEXT:
+            {
+            if constexpr (SSZ == 1)
+                return (uint64_t)(int64_t)(int8_t)raw;
+            else if constexpr (SSZ == 2)
+                return (uint64_t)(int64_t)(int16_t)raw;
+            else if constexpr (SSZ == 4)
+                return (uint64_t)(int64_t)(int32_t)raw;
+            else
+                return raw;
+            }
+        case PACK_F2F:
+            {
+            if constexpr (SSZ == 8 && DSZ == 4)
+                return (uint64_t)__float_as_uint((float)__longlong_as_double((long long)raw)); // RNE
+            else if constexpr (SSZ == 4 && DSZ == 8)
+                return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)raw));
+            else
+                return raw;
+            }
+        case PACK_U2F:
+            {
+            if constexpr (DSZ == 4)
+                return (uint64_t)__float_as_uint((float)(uint32_t)raw);
+            else
+                return (uint64_t)__double_as_longlong((double)(uint32_t)raw);
+            }
+        case PACK_S2F:
+            {
+            int32_t v;
+            if constexpr (SSZ == 1)
+                v = (int8_t)raw;
+            else if constexpr (SSZ == 2)
+                v = (int16_t)raw;
+            else
+                v = (int32_t)raw;
+            if constexpr (DSZ == 4)
+                return (uint64_t)__float_as_uint((float)v);
+            else
+                return (uint64_t)__double_as_longlong((double)v);
+            }
+        }
+    }
+
+// Stream the re-packed tile of one output chunk from LDS to global memory:
+// 16 bytes per lane per store, lanes consecutive => each wave store covers 1 KiB.
+template<int SSZ, int DSZ>
+__device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uint32_t rows,
+                                          uint32_t stride_elems, uint64_t row0)
+    {
+    constexpr uint32_t EPT = 16 / DSZ; // elements per 16-byte vector
+    const uint32_t M = o.M;
+    const uint32_t nelem = rows * M;
+    const uint32_t nvec = nelem / EPT;
+    char* gdst = (char*)o.dst + row0 * (uint64_t)M * DSZ;
+    const uint32_t kind = o.kind;
+    const uint32_t col0 = o.col0;
+
+    for (uint32_t v = threadIdx.x; v < nvec; v += PACK_THREADS)
+        {
+        uint32_t e = v * EPT;
+        // row = e / M via multiply-high (exact for e < 2^32 / M, host guarantees it)
+        uint32_t row = (M == 1) ? e : __umulhi(e, o.magic);
+        uint32_t col = e - row * M;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < EPT; k++)
+            {
+            uint64_t raw = lds_load<SSZ>(lds + (size_t)(row * stride_elems + col0 + col) * SSZ);
+            uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
+            if constexpr (DSZ == 8)
+                {
+                w[2 * k] = (uint32_t)val;
+                w[2 * k + 1] = (uint32_t)(val >> 32);
+                }
+            else if constexpr (DSZ == 4)
+                w[k] = (uint32_t)val;
+            else if constexpr (DSZ == 2)
+                w[k >> 1] |= ((uint32_t)val & 0xffffu) << (16 * (k & 1));
+            else
+                w[k >> 2] |= ((uint32_t)val & 0xffu) << (8 * (k & 3));
+            if (++col == M)
+                {
+                col = 0;
+                row++;
+                }
+            }
+        u32x4 out = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(out, (u32x4*)(gdst + (size_t)v * 16));
+        }
+    // ragged end of the last tile: element-wise
+    for (uint32_t e = nvec * EPT + threadIdx.x; e < nelem; e += PACK_THREADS)
+        {
+        uint32_t row = (M == 1) ? e : __umulhi(e, o.magic);
+        uint32_t col = e - row * M;
+        uint64_t raw = lds_load<SSZ>(lds + (size_t)(row * stride_elems + col0 + col) * SSZ);
+        uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
+        char* p = gdst + (size_t)e * DSZ;
+        if constexpr (DSZ == 8)
+            *(uint64_t*)p = val;
+        else if constexpr (DSZ == 4)
+            *(uint32_t*)p = (uint32_t)val;
+        else if constexpr (DSZ == 2)
+            *(uint16_t*)p = (uint16_t)val;
+        else
+            *(uint8_t*)p = (uint8_t)val;
+        }
+    }
+
+template<int SSZ>
+__device__ __forceinline__ void emit_dispatch(const PackOut& o, const char* lds, uint32_t rows,
+                                              uint32_t stride_elems, uint64_t row0)
+    {
+    switch (o.dsz)
+        {
+        case 1: emit_tile<SSZ, 1>(o, lds, rows, stride_elems, row0); break;
+        case 2: emit_tile<SSZ, 2>(o, lds, rows, stride_elems, row0); break;
+        case 4: emit_tile<SSZ, 4>(o, lds, rows, stride_elems, row0); break;
+        default: emit_tile<SSZ, 8>(o, lds, rows, stride_elems, row0); break;
+        }
+    }
+
+// Fused multi-field pack.  One workgroup owns a tile of `tile_rows` particles at a time and
+// walks all source groups for it.
+__global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
+    {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t TILE = args.tile_rows;
+
+    for (uint64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x)
+        {
+        const uint64_t row0 = tile * TILE;
+        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+
+        for (uint32_t gi = 0; gi < args.n_groups; gi++)
+            {
+            const PackGroup& g = args.g[gi];
+            const uint32_t rowbytes = g.rowbytes;
+
+            if (g.order == nullptr)
+                {
+                // linear tile: rows*rowbytes contiguous bytes, 16-byte aligned start
+                const char* gsrc = (const char*)g.src + row0 * rowbytes;
+                const uint32_t nbytes = rows * rowbytes;
+                const uint32_t nvec = nbytes >> 4;
+                uint32_t v = tid;
+                // four independent 16-byte loads in flight per lane
+                for (; v + 3 * PACK_THREADS < nvec; v += 4 * PACK_THREADS)
+                    {
+                    u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+                    u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + PACK_THREADS);
+                    u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * PACK_THREADS);
+                    u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * PACK_THREADS);
+                    ((u32x4*)lds)[v] = a;
+                    ((u32x4*)lds)[v + PACK_THREADS] = b;
+                    ((u32x4*)lds)[v + 2 * PACK_THREADS] = c;
+                    ((u32x4*)lds)[v + 3 * PACK_THREADS] = d;
+                    }
+                for (; v < nvec; v += PACK_THREADS)
+                    ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+                for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
+                    lds[b] = gsrc[b];
+                }
+            else
+                {
+                // gathered tile: row i of the tile comes from source row order[row0 + i]
+                const uint32_t* ord = g.order + row0;
+                if (rowbytes == 16)
+                    {
+                    for (uint32_t i = tid; i < rows; i += PACK_THREADS)
+                        ((u32x4*)lds)[i] = *((const u32x4*)g.src + ord[i]);
+                    }
+                else if (rowbytes == 32)
+                    {
+                    for (uint32_t i = tid; i < 2 * rows; i += PACK_THREADS)
+                        ((u32x4*)lds)[i] = *((const u32x4*)g.src + 2 * (uint64_t)ord[i >> 1] + (i & 1));
+                    }
+                else if ((rowbytes & 3) == 0)
+                    {
+                    const uint32_t wpr = rowbytes >> 2;
+                    const uint32_t nw = rows * wpr;
+                    for (uint32_t i = tid; i < nw; i += PACK_THREADS)
+                        {
+                        uint32_t r = i / wpr, c = i - r * wpr;
+                        ((uint32_t*)lds)[i] = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
+                        }
+                    }
+                else
+                    {
+                    const uint32_t nb = rows * rowbytes;
+                    for (uint32_t i = tid; i < nb; i += PACK_THREADS)
+                        {
+                        uint32_t r = i / rowbytes, c = i - r * rowbytes;
+                        lds[i] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
+                        }
+                    }
+                }
+            __syncthreads();
+
+            for (uint32_t oi = 0; oi < g.n_out; oi++)
+                {
+                const PackOut& o = g.out[oi];
+                switch (g.ssz)
+                    {
+                    case 1: emit_dispatch<1>(o, lds, rows, g.stride, row0); break;
+                    case 2: emit_dispatch<2>(o, lds, rows, g.stride, row0); break;
+                    case 4: emit_dispatch<4>(o, lds, rows, g.stride, row0); break;
+                    default: emit_dispatch<8>(o, lds, rows, g.stride, row0); break;
+                    }
+                }
+            __syncthreads();
+            }
+        }
+    }
+
+// Fallback for operands the tiled kernel cannot take (unaligned pointers, very wide
+// rows): one output element per lane, grid-stride.  Correct for everything, not tuned.
+__global__ __launch_bounds__(PACK_THREADS) void pack_generic_kernel(const PackGenericArgs a)
+    {
+    const uint64_t total = a.N * a.M;
+    for (uint64_t e = (uint64_t)blockIdx.x * PACK_THREADS + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * PACK_THREADS)
+        {
+        uint64_t row = e / a.M;
+        uint32_t col = (uint32_t)(e - row * a.M);
+        uint64_t srow = a.order ? a.order[row] : row;
+        const char* sp = (const char*)a.src + (srow * a.stride + a.col0 + col) * a.ssz;
+        uint64_t raw = 0;
+        for (uint32_t b = 0; b < a.ssz; b++)
+            raw |= (uint64_t)(uint8_t)sp[b] << (8 * b);
+        uint64_t val;
+        switch (a.ssz)
+            {
+            case 1: val = a.dsz == 8 ? convert_elem<1, 8>(raw, a.kind) : convert_elem<1, 4>(raw, a.kind); break;
+            case 2: val = a.dsz == 8 ? convert_elem<2, 8>(raw, a.kind) : convert_elem<2, 4>(raw, a.kind); break;
+            case 4: val = a.dsz == 8 ? convert_elem<4, 8>(raw, a.kind) : convert_elem<4, 4>(raw, a.kind); break;
+            default: val = a.dsz == 4 ? convert_elem<8, 4>(raw, a.kind) : convert_elem<8, 8>(raw, a.kind); break;
+            }
+        char* dp = (char*)a.dst + e * a.dsz;
+        for (uint32_t b = 0; b < a.dsz; b++)
+            dp[b] = (char)(val >> (8 * b));
+        }
+    }
+
+// ------------------------------------------------------------------ select (compaction)
+#define SEL_THREADS 256
+#define SEL_PER_THREAD 16
+#define SEL_PER_BLOCK (SEL_THREADS * SEL_PER_THREAD)
+
+// number of non-zero flag bytes among the 16 this lane owns
+__device__ __forceinline__ uint32_t sel_load16(const uint8_t* flags, uint64_t base, uint64_t N, uint32_t* mask)
+    {
+    uint32_t m = 0;
+    if (base + SEL_PER_THREAD <= N && ((uintptr_t)(flags + base) & 15) == 0)
+        {
+        u32x4 v = *(const u32x4*)(flags + base);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            m |= (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) != 0 ? 1u : 0u) << k;
+        }
+    else
+        {
+        for (int k = 0; k < 16; k++)
+            if (base + k < N && flags[base + k] != 0)
+                m |= 1u << k;
+        }
+    *mask = m;
+    return (uint32_t)__popc(m);
+    }
+
+// inclusive scan of one value per lane across the 64-lane wavefront
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+    {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+        {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d)
+            x += y;
+        }
+    return x;
+    }
+
+__global__ __launch_bounds__(SEL_THREADS) void select_count_kernel(const uint8_t* flags, uint64_t N,
+                                                                   uint32_t* block_counts)
+    {
+    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
+    uint32_t mask;
+    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
+    uint32_t inc = wave_inclusive_scan(c);
+    if ((threadIdx.x & 63) == 63)
+        wave_sums[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    }
+
+// exclusive scan of the block counts by ONE workgroup; also writes the total
+__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
+                                                                  uint64_t* block_offsets,
+                                                                  uint64_t* out_count)
+    {
+    __shared__ uint64_t carry;
+    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += SEL_THREADS)
+        {
+        uint32_t i = b0 + threadIdx.x;
+        uint32_t c = i < n_blocks ? block_counts[i] : 0;
+        uint32_t inc = wave_inclusive_scan(c);
+        if ((threadIdx.x & 63) == 63)
+            wave_sums[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+            wave_off += wave_sums[w];
+        if (i < n_blocks)
+            block_offsets[i] = carry + wave_off + inc - c;
+        __syncthreads();
+        if (threadIdx.x == SEL_THREADS - 1)
+            carry += (uint64_t)wave_off + inc;
+        __syncthreads();
+        }
+    if (threadIdx.x == 0)
+        *out_count = carry;
+    }
+
+__global__ __launch_bounds__(SEL_THREADS) void select_scatter_kernel(const uint8_t* flags, uint64_t N,
+                                                                     const uint64_t* block_offsets,
+                                                                     uint32_t* out_index)
+    {
+    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
+    uint32_t mask = 0;
+    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
+    uint32_t inc = wave_inclusive_scan(c);
+    if ((threadIdx.x & 63) == 63)
+        wave_sums[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+        wave_off += wave_sums[w];
+    uint64_t pos = block_offsets[blockIdx.x] + wave_off + inc - c;
+    while (mask)
+        {
+        int k = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        out_index[pos++] = (uint32_t)(base + (uint64_t)k);
+        }
+    }
+
+// ------------------------------------------------------------------ host side
+
+static uint32_t conv_kind(uint32_t src_type, uint32_t dst_type, uint32_t bitcast)
+    {
+    const bool s_int = src_type <= PGSD_TYPE_INT64, d_int = dst_type <= PGSD_TYPE_INT64;
+    const size_t ssz = sizeof_type(src_type), dsz = sizeof_type(dst_type);
+    if (bitcast || src_type == dst_type)
+        return PACK_BITS;
+    if (s_int && d_int)
+        {
+        const bool s_signed = src_type >= PGSD_TYPE_INT8;
+        return (dsz > ssz && s_signed) ? PACK_SEXT : PACK_BITS;
+        }
+    if (!s_int && !d_int)
+        return PACK_F2F;
+    // integer -> float (checked by the caller: source <= 32 bit)
+    return src_type >= PGSD_TYPE_INT8 ? PACK_S2F : PACK_U2F;
+    }
+
+static bool job_valid(const pgsd_pack_job& j)
+    {
+    const size_t ssz = sizeof_type(j.src.src_type), dsz = sizeof_type(j.dst_type);
+    if (!j.dst || !j.src.src || ssz == 0 || dsz == 0 || j.M == 0 || j.src.src_col0 + j.M > j.src.src_stride)
+        return false;
+    const bool s_int = j.src.src_type <= PGSD_TYPE_INT64, d_int = j.dst_type <= PGSD_TYPE_INT64;
+    if (j.src.bitcast)
+        return dsz <= ssz;
+    if (!s_int && d_int)
+        return false;
+    if (s_int && !d_int && ssz == 8)
+        return false;
+    return true;
+    }
+
+uint64_t pack_algorithmic_bytes_in(const pgsd_pack_job& j, uint64_t N)
+    {
+    return N * (uint64_t)j.M * sizeof_type(j.src.src_type) + (j.src.order ? N * 4 : 0);
+    }
+
+uint64_t pack_bytes_out(const pgsd_pack_job& j, uint64_t N)
+    {
+    return N * (uint64_t)j.M * sizeof_type(j.dst_type);
+    }
+
+static int g_num_cus = 0;
+
+static int num_cus()
+    {
+    if (g_num_cus == 0)
+        {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0)
+            g_num_cus = 256;
+        }
+    return g_num_cus;
+    }
+
+int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
+    {
+    if (n_jobs == 0 || N == 0)
+        return PGSD_SUCCESS;
+    for (uint32_t i = 0; i < n_jobs; i++)
+        if (!job_valid(jobs[i]))
+            {
+            if (err)
+                *err = "invalid pack job (types, columns or pointers)";
+            return PGSD_ERROR_INVALID_ARGUMENT;
+            }
+
+    std::vector<bool> done(n_jobs, false);
+    // jobs the tiled kernel cannot take go through the generic kernel
+    for (uint32_t i = 0; i < n_jobs; i++)
+        {
+        const pgsd_pack_job& j = jobs[i];
+        const size_t ssz = sizeof_type(j.src.src_type);
+        const uint64_t rowbytes = (uint64_t)j.src.src_stride * ssz;
+        const bool aligned = (((uintptr_t)j.dst | (uintptr_t)j.src.src) & 15) == 0
+                             && (j.src.order == nullptr || ((uintptr_t)j.src.order & 3) == 0);
+        if (!aligned || rowbytes > PACK_MAX_ROWBYTES || j.M > PACK_MAX_M || N * rowbytes >= (1ull << 62))
+            {
+            PackGenericArgs a;
+            a.dst = j.dst;
+            a.src = j.src.src;
+            a.order = j.src.order;
+            a.N = N;
+            a.M = j.M;
+            a.stride = j.src.src_stride;
+            a.col0 = j.src.src_col0;
+            a.ssz = (uint32_t)ssz;
+            a.dsz = (uint32_t)sizeof_type(j.dst_type);
+            a.kind = conv_kind(j.src.src_type, j.dst_type, j.src.bitcast);
+            uint64_t total = N * j.M;
+            uint64_t blocks = (total + PACK_THREADS - 1) / PACK_THREADS;
+            uint64_t cap = (uint64_t)num_cus() * 8;
+            if (blocks > cap)
+                blocks = cap;
+            hipLaunchKernelGGL(pack_generic_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), 0, stream, a);
+            done[i] = true;
+            }
+        }
+
+    // group the remaining jobs by source array and launch in batches that fit PackArgs
+    uint32_t next = 0;
+    while (true)
+        {
+        PackArgs args;
+        memset(&args, 0, sizeof(args));
+        args.N = N;
+        uint32_t max_rowbytes = 0;
+        bool any = false;
+        for (uint32_t i = next; i < n_jobs; i++)
+            {
+            if (done[i])
+                continue;
+            const pgsd_pack_job& j = jobs[i];
+            const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type);
+            // find a group with the same source
+            int gi = -1;
+            for (uint32_t k = 0; k < args.n_groups; k++)
+                if (args.g[k].src == j.src.src && args.g[k].order == j.src.order && args.g[k].ssz == ssz
+                    && args.g[k].stride == j.src.src_stride && args.g[k].n_out < PACK_MAX_OUT)
+                    gi = (int)k;
+            if (gi < 0)
+                {
+                if (args.n_groups == PACK_MAX_GROUPS)
+                    continue; // next batch
+                gi = (int)args.n_groups++;
+                PackGroup& g = args.g[gi];
+                g.src = j.src.src;
+                g.order = j.src.order;
+                g.ssz = ssz;
+                g.stride = j.src.src_stride;
+                g.rowbytes = j.src.src_stride * ssz;
+                g.n_out = 0;
+                max_rowbytes = std::max(max_rowbytes, g.rowbytes);
+                }
+            PackGroup& g = args.g[gi];
+            PackOut& o = g.out[g.n_out++];
+            o.dst = j.dst;
+            o.M = j.M;
+            o.col0 = j.src.src_col0;
+            o.dsz = (uint32_t)sizeof_type(j.dst_type);
+            o.kind = conv_kind(j.src.src_type, j.dst_type, j.src.bitcast);
+            o.magic = j.M == 1 ? 0u : (uint32_t)(((1ull << 32) + j.M - 1) / j.M);
+            done[i] = true;
+            any = true;
+            }
+        if (!any)
+            break;
+        // tile: as many rows as fit PACK_LDS_BYTES, power of two in [16, 1024]
+        uint32_t tile = 1024;
+        while (tile > 16 && (uint64_t)tile * max_rowbytes > PACK_LDS_BYTES)
+            tile >>= 1;
+        args.tile_rows = tile;
+        args.n_tiles = (N + tile - 1) / tile;
+        uint64_t blocks = args.n_tiles;
+        uint64_t cap = (uint64_t)num_cus() * 8;
+        if (blocks > cap)
+            blocks = cap;
+        size_t lds_bytes = (size_t)tile * max_rowbytes;
+        lds_bytes = (lds_bytes + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream,
+                           args);
+        while (next < n_jobs && done[next])
+            next++;
+        if (next == n_jobs)
+            break;
+        }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        {
+        if (err)
+            *err = std::string("pack kernel launch failed: ") + hipGetErrorString(e);
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
+    } // namespace pgsd_amd
+
+using namespace pgsd_amd;
+
+extern "C" int pgsd_device_available(void)
+    {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return 0;
+        }
+    return n > 0 ? 1 : 0;
+    }
+
+extern "C" int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream)
+    {
+    if (n_jobs > 0 && !jobs)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_pack_fields: no HIP device visible (the HIP path has no CPU fallback)");
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    std::string err;
+    int rc = launch_pack(n_jobs, jobs, N, (hipStream_t)stream, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
+
+extern "C" size_t pgsd_select_workspace_bytes(uint64_t N)
+    {
+    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+    if (n_blocks == 0)
+        n_blocks = 1;
+    // block_counts (u32) rounded to 8 bytes + block_offsets (u64)
+    return (size_t)(((n_blocks * 4 + 7) & ~7ull) + n_blocks * 8);
+    }
+
+extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
+                                void* workspace, void* stream_)
+    {
+    if (!out_count || !workspace || (N > 0 && (!flags || !out_index)) || N >= (1ull << 32))
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_select_rows: no HIP device visible (the HIP path has no CPU fallback)");
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    hipStream_t stream = (hipStream_t)stream_;
+    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+    if (N == 0)
+        {
+        (void)hipMemsetAsync(out_count, 0, sizeof(uint64_t), stream);
+        }
+    else
+        {
+        uint32_t* block_counts = (uint32_t*)workspace;
+        uint64_t* block_offsets = (uint64_t*)((char*)workspace + ((n_blocks * 4 + 7) & ~7ull));
+        hipLaunchKernelGGL(select_count_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags, N,
+                           block_counts);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, block_counts,
+                           (uint32_t)n_blocks, block_offsets, out_count);
+        hipLaunchKernelGGL(select_scatter_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags,
+                           N, block_offsets, out_index);
+        }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        {
+        set_last_error(std::string("select kernel launch failed: ") + hipGetErrorString(e));
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }

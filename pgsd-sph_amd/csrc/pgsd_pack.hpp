@@ -1,0 +1,83 @@
+// pgsd_pack.hpp -- kernel argument blocks of the pack kernels (pgsd_pack.hip) and the
+// host-side launcher shared with the device pipeline (pgsd_device.cpp).
+#ifndef PGSD_PACK_HPP
+#define PGSD_PACK_HPP
+
+#include "pgsd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+namespace pgsd_amd
+    {
+enum
+    {
+    PACK_MAX_GROUPS = 8,       // distinct source arrays per launch
+    PACK_MAX_OUT = 6,          // chunks fed from one source array
+    PACK_LDS_BYTES = 32768,    // LDS tile budget per workgroup (>= 5 workgroups per CU)
+    PACK_MAX_ROWBYTES = 2048,  // wider source rows take the generic kernel
+    PACK_MAX_M = 1024
+    };
+
+// element conversions (wave-uniform per output)
+enum
+    {
+    PACK_BITS = 0, // copy the low destination-size bytes (same type, narrowing, zero-extension, bitcast)
+    PACK_SEXT = 1, // sign-extend a narrower signed integer
+    PACK_F2F = 2,  // f64 -> f32 (round to nearest even) or f32 -> f64
+    PACK_U2F = 3,  // unsigned integer (<= 32 bit) -> f32 / f64
+    PACK_S2F = 4   // signed integer (<= 32 bit) -> f32 / f64
+    };
+
+struct PackOut
+    {
+    void* dst;      // chunk buffer, 16-byte aligned
+    uint32_t M;     // columns of the chunk
+    uint32_t col0;  // first source column
+    uint32_t dsz;   // bytes per chunk element
+    uint32_t kind;  // PACK_*
+    uint32_t magic; // ceil(2^32 / M) for row = e / M (0 when M == 1)
+    uint32_t pad;
+    };
+
+struct PackGroup
+    {
+    const void* src;       // source array, 16-byte aligned
+    const uint32_t* order; // gather index or nullptr
+    uint32_t rowbytes;     // stride * ssz
+    uint32_t ssz;          // bytes per source element
+    uint32_t stride;       // elements per source row
+    uint32_t n_out;
+    PackOut out[PACK_MAX_OUT];
+    };
+
+struct PackArgs
+    {
+    uint64_t N;
+    uint64_t n_tiles;
+    uint32_t tile_rows;
+    uint32_t n_groups;
+    PackGroup g[PACK_MAX_GROUPS];
+    };
+
+struct PackGenericArgs
+    {
+    void* dst;
+    const void* src;
+    const uint32_t* order;
+    uint64_t N;
+    uint32_t M, stride, col0, ssz, dsz, kind;
+    };
+
+// Enqueue the pack of `n_jobs` fields of N rows each on `stream`. Returns a pgsd_error.
+int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
+
+// algorithmic traffic of one job: bytes that must be read (needed columns only, plus the
+// gather index) and chunk bytes written
+uint64_t pack_algorithmic_bytes_in(const pgsd_pack_job& j, uint64_t N);
+uint64_t pack_bytes_out(const pgsd_pack_job& j, uint64_t N);
+    } // namespace pgsd_amd
+
+#endif

@@ -1,0 +1,50 @@
+"""Helpers to build and drive the product (libpgsd_amd.so) from the tests."""
+import os
+import subprocess
+import uuid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pgsd-sph_amd", "csrc")
+LIB = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
+DRIVER = os.path.join(CSRC, "build", "scenario_driver")
+
+_built = False
+
+
+def build():
+    """make -C pgsd-sph_amd/csrc (no-op when up to date)."""
+    global _built
+    if not _built:
+        subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
+        _built = True
+    return LIB
+
+
+def run_driver(script, out_path, P, timeout=120):
+    """Replay a scenario through the product's C ABI with P processes (shm communicator).
+
+    Returns rank 0's stdout lines."""
+    build()
+    name = "pgsdtest_%s" % uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(P):
+        env = dict(os.environ, PGSD_RANK=str(r), PGSD_NRANKS=str(P), PGSD_SHM_NAME=name)
+        procs.append(subprocess.Popen([DRIVER, script, out_path], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = None
+    try:
+        out, _ = procs[0].communicate(timeout=timeout)
+        for p in procs[1:]:
+            p.wait(timeout=timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            os.unlink("/dev/shm/" + name)
+        except OSError:
+            pass
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            raise RuntimeError("scenario driver rank %d exited with %s" % (r, p.returncode))
+    return [ln for ln in out.decode().splitlines() if ln.strip()]
