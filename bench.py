@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- snapshot pack+write throughput of the MI355X-native PGSD writer.
+
+One "step" = one frame of the hot path on one batch of synthetic particle data that is
+already resident in HBM: RCCL allgather of the per-rank row counts (file offsets), fused
+HIP pack of position / velocity / typeid from HOOMD-style float4 arrays, hipMemcpyAsync to
+pinned slabs, pwrite into one shared GSD file on tmpfs, index commit (pgsd_end_frame).
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches it with torch.distributed.run (one rank per GPU); ranks share
+ONE output file, each writing its own partition (weak scaling: 10 M particles per GPU).
+Rank 0 prints one JSON line (contract in the task description) with `roofline` for the pack
+kernel and `cpu_baseline` for the CPU restatement of the reference path (oracle/, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pgsd-sph_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+ALGO_BYTES_PER_PARTICLE = 56   # read pos.xyz + vel.xyz + typeid (28 B) + write the three chunks (28 B)
+PAYLOAD_BYTES_PER_PARTICLE = 28
+
+
+def cpu_baseline(n_particles, frames, out_dir):
+    """Time the CPU restatement of the reference path (oracle/, kind="port") on host cores:
+    pack float4 -> N x 3 with the C loop a CPU caller runs, then the reference's
+    write_chunk/end_frame sequence, single thread like one MPI rank of the reference."""
+    import numpy as np
+    import scenario as S
+    lib = S.oracle_lib()
+    rng = np.random.default_rng(1234)
+    pos = ((rng.random((n_particles, 4), dtype=np.float32) - 0.5) * 100.0).astype(np.float32)
+    vel = rng.standard_normal((n_particles, 4), dtype=np.float32)
+    tid = rng.permutation(n_particles).astype(np.uint32).reshape(-1, 1)
+    o_pos = np.empty((n_particles, 3), dtype=np.float32)
+    o_vel = np.empty((n_particles, 3), dtype=np.float32)
+    path = os.path.join(out_dir, "pgsd_bench_cpu_%d.gsd" % os.getpid())
+    rc = ctypes.c_int(0)
+    h = lib.oracle_create_and_open(path.encode(), 1, b"bench", b"hoomd", lib.oracle_make_version(1, 4), 1, 0,
+                                   ctypes.byref(rc))
+    assert rc.value == 0
+
+    def frame(i):
+        lib.oracle_pack_rows(o_pos.ctypes.data, 9, pos.ctypes.data, 9, n_particles, 3, 4, 0, None, 0)
+        lib.oracle_pack_rows(o_vel.ctypes.data, 9, vel.ctypes.data, 9, n_particles, 3, 4, 0, None, 0)
+        step = np.array([[i]], dtype=np.uint64)
+        S.oracle_write_chunk(lib, h, "configuration/step", 4, [step], 1, 1, 1, [0], [1], False)
+        for name, arr, t, M in (("particles/position", o_pos, 9, 3), ("particles/velocity", o_vel, 9, 3),
+                                ("particles/typeid", tid, 3, 1)):
+            S.oracle_write_chunk(lib, h, name, t, [arr], M, n_particles, M, [0], [n_particles * M], True)
+        assert lib.oracle_end_frame(h) == 0
+
+    frame(0)  # warm-up (first touch of the output arrays and the file)
+    t0 = time.perf_counter()
+    for i in range(frames):
+        frame(i + 1)
+    dt = time.perf_counter() - t0
+    lib.oracle_close(h)
+    os.unlink(path)
+    gbs = frames * n_particles * PAYLOAD_BYTES_PER_PARTICLE / dt / 1e9
+    return {"value": round(gbs, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d frames x %d particles (pos+vel+typeid), float4 -> chunk pack in C + "
+                      "reference write sequence, 1 thread, file on %s" % (frames, n_particles, out_dir)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
+    ap.add_argument("--dir", default=os.environ.get("PGSD_BENCH_DIR", "/dev/shm"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-mib", type=int, default=0)
+    ap.add_argument("--slabs", type=int, default=0)
+    ap.add_argument("--writers", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import pgsd.fl as fl
+    import pgsd.dist as pdist
+    comm_backend = pdist.init_from_torch(device=local_rank) if world > 1 else "self"
+
+    N = args.particles
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
+    vel = torch.randn((N, 4), generator=g, device="cuda")
+    tid = torch.randperm(N, generator=g, device="cuda").to(torch.int32)
+    fields = [("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
+              ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
+              ("particles/typeid", fl.DeviceField.from_tensor(tid, out_dtype=np.uint32))]
+
+    path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
+    f.configure_device(device=local_rank, slab_bytes=args.slab_mib << 20, n_slabs=args.slabs,
+                       n_writers=args.writers, profile=True)
+
+    def step(i):
+        # per-rank file offsets: allgather of the local row counts (RCCL over xGMI for N > 1)
+        counts, row0, n_global = pdist.partition_rows(N)
+        f.write_chunk("configuration/step", np.array([i], dtype=np.uint64), write_all=False)
+        f.write_chunks(fields, offset=counts, rank=rank)
+        f.end_frame()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    f.device_stats(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    stats = f.device_stats()
+    f.close()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        pk = torch.tensor([stats["pack_ms"] / max(stats["pack_launches"], 1)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pk, op=dist.ReduceOp.MAX)
+        pack_ms = float(pk.item())
+    else:
+        pack_ms = stats["pack_ms"] / max(stats["pack_launches"], 1)
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_bytes = world * args.steps * N * PAYLOAD_BYTES_PER_PARTICLE
+    value = total_bytes / dt / 1e9
+    achieved = ALGO_BYTES_PER_PARTICLE * N / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
+    out = {
+        "metric": "snapshot pack+write GB/s at 10M particles/GPU",
+        "value": round(value, 3),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%d particles/GPU, position+velocity+typeid from float4/int32 HBM arrays, "
+                               "%s allgather of row counts, one shared GSD file on %s"
+                               % (N, comm_backend, args.dir),
+                   "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * PAYLOAD_BYTES_PER_PARTICLE,
+                   "parallelism": "particle-partition x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "pack_tiles_kernel", "avg_ms": round(pack_ms, 5),
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE * N},
+        "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
+                     "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, 8, args.dir)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

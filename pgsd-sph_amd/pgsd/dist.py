@@ -1,0 +1,120 @@
+"""Install the communicator the file layer uses (the role of MPI_COMM_WORLD in the reference,
+pgsd.c:106-202) from a ``torch.distributed`` process group.
+
+* GPU ranks (backend ``nccl`` = RCCL on ROCm): the library's native RCCL back end is used.
+  ``torch.distributed`` only distributes the 128-byte ncclUniqueId; afterwards every
+  allgather of the write path (row counts -> file offsets) is one ``ncclAllGather`` over xGMI
+  issued from C++ on a private HIP stream.
+* CPU ranks (backend ``gloo``, used by the multi-process tests): a host-callback back end
+  that forwards to ``torch.distributed.all_gather``.
+* A single process needs nothing: the default communicator is "self".
+"""
+import ctypes
+
+import numpy
+
+from . import _lib
+from ._lib import lib
+
+_keep = {}
+
+
+def init_self():
+    lib.pgsd_comm_init_self()
+    _keep.clear()
+
+
+def init_shm(name, rank, size):
+    """Ranks of one node meeting in /dev/shm/<name> (no torch needed)."""
+    rc = lib.pgsd_comm_init_shm(name.encode(), rank, size)
+    if rc != 0:
+        raise RuntimeError("pgsd_comm_init_shm failed: " + _lib.last_error())
+
+
+def init_from_torch(group=None, device=None, prefer_rccl=True):
+    """Use an initialised ``torch.distributed`` group. Returns the back end name."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        init_self()
+        return "self"
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    if size == 1:
+        init_self()
+        return "self"
+    backend = dist.get_backend(group)
+    if prefer_rccl and backend == "nccl" and torch.cuda.is_available():
+        if device is None:
+            device = torch.cuda.current_device()
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % device)
+        if rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            rc = lib.pgsd_comm_rccl_unique_id(buf)
+            if rc != 0:
+                raise RuntimeError("pgsd_comm_rccl_unique_id failed: " + _lib.last_error())
+            uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        dist.broadcast(uid, src=0, group=group)
+        host = bytes(uid.cpu().tolist())
+        rc = lib.pgsd_comm_init_rccl(host, rank, size, int(device))
+        if rc != 0:
+            raise RuntimeError("pgsd_comm_init_rccl failed: " + _lib.last_error())
+        return "rccl"
+
+    on_gpu = backend == "nccl"
+
+    def _allgather(ctx, send, recv, nbytes):
+        try:
+            src = numpy.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+            t = torch.from_numpy(src.copy())
+            if on_gpu:
+                t = t.cuda()
+            out = [torch.empty_like(t) for _ in range(size)]
+            dist.all_gather(out, t, group=group)
+            dst = numpy.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)),
+                                           shape=(nbytes * size,))
+            for j, o in enumerate(out):
+                dst[j * nbytes:(j + 1) * nbytes] = o.cpu().numpy()
+            return 0
+        except Exception:  # pragma: no cover
+            return -1
+
+    def _barrier(ctx):
+        try:
+            dist.barrier(group=group)
+            return 0
+        except Exception:  # pragma: no cover
+            return -1
+
+    cb_ag = _lib.ALLGATHER_FN(_allgather)
+    cb_bar = _lib.BARRIER_FN(_barrier)
+    comm = _lib.Comm()
+    comm.ctx = None
+    comm.rank = rank
+    comm.size = size
+    comm.allgather = cb_ag
+    comm.barrier = cb_bar
+    rc = lib.pgsd_comm_set_default(ctypes.byref(comm))
+    if rc != 0:
+        raise RuntimeError("pgsd_comm_set_default failed")
+    _keep["cb"] = (cb_ag, cb_bar, comm)
+    return "torch-" + backend
+
+
+def finalize():
+    lib.pgsd_comm_finalize()
+    _keep.clear()
+
+
+def partition_rows(n_local):
+    """Allgather every rank's row count over the installed communicator.
+
+    Returns ``(counts, row0, n_global)``; ``counts`` is the array ``write_chunk`` takes as
+    ``offset`` (fl.pyx:594-598)."""
+    size = lib.pgsd_comm_size()
+    counts = (ctypes.c_uint64 * size)()
+    row0 = ctypes.c_uint64(0)
+    ng = ctypes.c_uint64(0)
+    rc = lib.pgsd_partition_rows(int(n_local), ctypes.byref(row0), ctypes.byref(ng), counts)
+    if rc != 0:
+        raise RuntimeError("pgsd_partition_rows failed: " + _lib.last_error())
+    return numpy.array(list(counts), dtype=numpy.uint64), int(row0.value), int(ng.value)

@@ -1,0 +1,274 @@
+"""Parity of the HIP pack / select kernels (called through the C ABI) against the CPU oracle.
+
+Bit-exact: the path is byte movement plus IEEE conversions with a single defined rounding
+(f64 -> f32 round-to-nearest-even), so no tolerance is needed anywhere.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SIZES = [1, 3, 63, 64, 65, 1000, 1023, 1024, 1025, 4099, 100003]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def empty_out(N, M, dt):
+    # poison so that unwritten bytes are caught
+    t = torch.empty((N * M * np.dtype(dt).itemsize + 64,), dtype=torch.uint8, device="cuda")
+    t.fill_(0xAB)
+    return t
+
+
+def check(out_t, expect):
+    got = out_t.cpu().numpy()
+    nbytes = expect.nbytes
+    assert got[:nbytes].tobytes() == expect.tobytes()
+    assert (got[nbytes:] == 0xAB).all(), "kernel wrote past the end of the chunk"
+
+
+@pytest.mark.parametrize("N", SIZES)
+def test_float4_to_position_velocity_typeid(N):
+    """HOOMD layout: pos = (x, y, z, type-as-int-bits), vel = (vx, vy, vz, mass)."""
+    rng = np.random.default_rng(N)
+    pos = G.rand_array(rng, (N, 4), np.float32)
+    vel = G.rand_array(rng, (N, 4), np.float32)
+    typeid = rng.integers(0, 5, size=N, dtype=np.uint32)
+    pos[:, 3] = typeid.view(np.float32)
+    dpos, dvel = dev(pos), dev(vel)
+    o_pos, o_vel = empty_out(N, 3, np.float32), empty_out(N, 3, np.float32)
+    o_tid, o_mass = empty_out(N, 1, np.uint32), empty_out(N, 1, np.float32)
+    G.hip_pack([(o_pos, np.float32, 3, dpos, 0, None, False),
+                (o_tid, np.uint32, 1, dpos, 3, None, True),
+                (o_vel, np.float32, 3, dvel, 0, None, False),
+                (o_mass, np.float32, 1, dvel, 3, None, False)], N)
+    check(o_pos, G.oracle_pack(pos, 3))
+    check(o_vel, G.oracle_pack(vel, 3))
+    check(o_tid, G.oracle_pack(pos, 1, col0=3, out_dtype=np.uint32, bitcast=True))
+    check(o_mass, G.oracle_pack(vel, 1, col0=3))
+    assert (o_tid.cpu().numpy()[:4 * N].view(np.uint32) == typeid).all()
+
+
+@pytest.mark.parametrize("N", [1, 64, 1000, 1025, 50001])
+def test_double4_to_float3(N):
+    """Scalar4 = double4 builds of HOOMD: f64 -> f32 with round-to-nearest-even,
+    including values that round to inf, denormals, and signed zeros."""
+    rng = np.random.default_rng(7 * N)
+    pos = G.rand_array(rng, (N, 4), np.float64)
+    special = np.array([0.0, -0.0, 1e-40, -1e-45, 3.5e38, -3.5e38, 1e39, np.inf, -np.inf,
+                        1.0 + 2.0 ** -24, 1.0 + 2.0 ** -24 + 2.0 ** -50, 16777217.0, 1e-320])
+    pos.reshape(-1)[:min(special.size, pos.size)] = special[:min(special.size, pos.size)]
+    d = dev(pos)
+    out = empty_out(N, 3, np.float32)
+    out64 = empty_out(N, 4, np.float64)
+    G.hip_pack([(out, np.float32, 3, d, 0, None, False), (out64, np.float64, 4, d, 0, None, False)], N)
+    check(out, G.oracle_pack(pos, 3, out_dtype=np.float32))
+    check(out64, G.oracle_pack(pos, 4))
+
+
+def test_nan_payload_preserved_in_same_type_copy():
+    N = 257
+    a = np.full((N, 4), np.nan, dtype=np.float32)
+    a.view(np.uint32)[:, 1] = 0x7FC12345
+    a.view(np.uint32)[:, 2] = 0xFF800001
+    d = dev(a)
+    out = empty_out(N, 3, np.float32)
+    G.hip_pack([(out, np.float32, 3, d, 0, None, False)], N)
+    check(out, G.oracle_pack(a, 3))
+
+
+@pytest.mark.parametrize("dt", ["uint8", "uint16", "uint32", "uint64", "int8", "int16", "int32", "int64",
+                                "float32", "float64"])
+@pytest.mark.parametrize("stride,M,col0", [(1, 1, 0), (3, 3, 0), (4, 3, 1), (7, 2, 5)])
+def test_all_types_same_type(dt, stride, M, col0):
+    N = 2051
+    rng = np.random.default_rng(abs(hash((dt, stride, M))) % 2 ** 32)
+    src = G.rand_array(rng, (N, stride), dt)
+    # torch lacks device copies for some unsigned types: move raw bytes
+    d = dev(src.view(np.uint8).reshape(N, -1))
+    out = empty_out(N, M, dt)
+    from pgsd import _lib
+    job = (_lib.PackJob * 1)()
+    job[0].dst = out.data_ptr()
+    job[0].dst_type = G.type_id(dt)
+    job[0].M = M
+    job[0].src.src = d.data_ptr()
+    job[0].src.src_type = G.type_id(dt)
+    job[0].src.src_stride = stride
+    job[0].src.src_col0 = col0
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    torch.cuda.synchronize()
+    check(out, G.oracle_pack(src, M, col0=col0))
+
+
+CONVERSIONS = [("int8", "int32"), ("int16", "int64"), ("uint8", "uint32"), ("uint16", "uint64"),
+               ("int32", "int8"), ("uint64", "uint16"), ("int32", "uint32"), ("int64", "int32"),
+               ("int32", "float32"), ("uint32", "float32"), ("int16", "float64"), ("uint8", "float32"),
+               ("float32", "float64"), ("float64", "float32"), ("int32", "float64"), ("uint32", "float64")]
+
+
+@pytest.mark.parametrize("sdt,ddt", CONVERSIONS)
+def test_conversions(sdt, ddt):
+    N, stride, M, col0 = 3001, 4, 3, 1
+    rng = np.random.default_rng(abs(hash((sdt, ddt))) % 2 ** 32)
+    src = G.rand_array(rng, (N, stride), sdt)
+    d = dev(src.view(np.uint8).reshape(N, -1))
+    out = empty_out(N, M, ddt)
+    from pgsd import _lib
+    job = (_lib.PackJob * 1)()
+    job[0].dst = out.data_ptr()
+    job[0].dst_type = G.type_id(ddt)
+    job[0].M = M
+    job[0].src.src = d.data_ptr()
+    job[0].src.src_type = G.type_id(sdt)
+    job[0].src.src_stride = stride
+    job[0].src.src_col0 = col0
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    torch.cuda.synchronize()
+    check(out, G.oracle_pack(src, M, col0=col0, out_dtype=ddt))
+
+
+def test_unsupported_conversion_is_rejected():
+    from pgsd import _lib
+    d = torch.zeros(16, dtype=torch.float32, device="cuda")
+    out = torch.zeros(16, dtype=torch.int32, device="cuda")
+    job = (_lib.PackJob * 1)()
+    job[0].dst = out.data_ptr()
+    job[0].dst_type = G.type_id("int32")
+    job[0].M = 1
+    job[0].src.src = d.data_ptr()
+    job[0].src.src_type = G.type_id("float32")
+    job[0].src.src_stride = 1
+    assert _lib.lib.pgsd_pack_fields(1, job, 16, None) == _lib.ERROR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("N", [1, 1000, 1025, 70001])
+@pytest.mark.parametrize("sdt,stride,M,ddt", [("float32", 4, 3, "float32"), ("float64", 4, 3, "float32"),
+                                              ("float32", 3, 3, "float32"), ("int32", 1, 1, "int32"),
+                                              ("uint8", 5, 2, "uint8")])
+def test_gather_in_tag_order(N, sdt, stride, M, ddt):
+    """order = HOOMD's reverse tag array: row i of the chunk is source row order[i]."""
+    rng = np.random.default_rng(N + stride)
+    Nsrc = N + 17
+    src = G.rand_array(rng, (Nsrc, stride), sdt)
+    order = rng.permutation(Nsrc)[:N].astype(np.uint32)
+    d = dev(src.view(np.uint8).reshape(Nsrc, -1))
+    dorder = dev(order.view(np.int32))
+    out = empty_out(N, M, ddt)
+    from pgsd import _lib
+    job = (_lib.PackJob * 1)()
+    job[0].dst = out.data_ptr()
+    job[0].dst_type = G.type_id(ddt)
+    job[0].M = M
+    job[0].src.src = d.data_ptr()
+    job[0].src.order = dorder.data_ptr()
+    job[0].src.src_type = G.type_id(sdt)
+    job[0].src.src_stride = stride
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    torch.cuda.synchronize()
+    check(out, G.oracle_pack(src, M, out_dtype=ddt, order=order))
+
+
+def test_unaligned_pointers_take_the_generic_kernel():
+    N = 5003
+    rng = np.random.default_rng(5)
+    src = G.rand_array(rng, (N, 4), np.float32)
+    raw = torch.empty(src.nbytes + 16, dtype=torch.uint8, device="cuda")
+    raw[4:4 + src.nbytes] = dev(src.view(np.uint8).reshape(-1))
+    out = empty_out(N + 1, 3, np.float32)
+    from pgsd import _lib
+    job = (_lib.PackJob * 1)()
+    job[0].dst = out.data_ptr() + 4
+    job[0].dst_type = G.type_id("float32")
+    job[0].M = 3
+    job[0].src.src = raw.data_ptr() + 4
+    job[0].src.src_type = G.type_id("float32")
+    job[0].src.src_stride = 4
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got[4:4 + N * 12].tobytes() == G.oracle_pack(src, 3).tobytes()
+    assert (got[:4] == 0xAB).all() and (got[4 + N * 12:] == 0xAB).all()
+
+
+def test_wide_rows():
+    N = 300
+    rng = np.random.default_rng(11)
+    src = G.rand_array(rng, (N, 96), np.float64)  # 768-byte rows
+    d = dev(src)
+    out = empty_out(N, 40, np.float32)
+    G.hip_pack([(out, np.float32, 40, d, 13, None, False)], N)
+    check(out, G.oracle_pack(src, 40, col0=13, out_dtype=np.float32))
+
+
+def test_more_fields_than_one_launch_holds():
+    N = 1500
+    rng = np.random.default_rng(3)
+    srcs = [G.rand_array(rng, (N, 4), np.float32) for _ in range(11)]
+    ds = [dev(s) for s in srcs]
+    outs = [empty_out(N, 3, np.float32) for _ in range(11)]
+    outs2 = [empty_out(N, 1, np.float32) for _ in range(11)]
+    jobs = []
+    for d, o, o2 in zip(ds, outs, outs2):
+        jobs.append((o, np.float32, 3, d, 0, None, False))
+        jobs.append((o2, np.float32, 1, d, 3, None, False))
+    G.hip_pack(jobs, N)
+    for s, o, o2 in zip(srcs, outs, outs2):
+        check(o, G.oracle_pack(s, 3))
+        check(o2, G.oracle_pack(s, 1, col0=3))
+
+
+@pytest.mark.parametrize("N,p", [(1, 1.0), (15, 0.5), (16, 0.5), (4096, 0.3), (4097, 0.9), (100003, 0.01),
+                                 (1 << 20, 0.5), (5000, 0.0), (5000, 1.0)])
+def test_select_rows(N, p):
+    from pgsd import _lib
+    rng = np.random.default_rng(N)
+    flags = (rng.random(N) < p).astype(np.uint8) * rng.integers(1, 255, size=N, dtype=np.uint8)
+    dflags = dev(flags)
+    out = torch.full((N + 8,), -1, dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.empty(_lib.lib.pgsd_select_workspace_bytes(N), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    rc = _lib.lib.pgsd_select_rows(dflags.data_ptr(), N, out.data_ptr(), count.data_ptr(), ws.data_ptr(), None)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    expect = np.nonzero(flags)[0].astype(np.int32)
+    assert int(count.item()) == expect.size
+    got = out.cpu().numpy()
+    assert (got[:expect.size] == expect).all()
+    assert (got[expect.size:] == -1).all()
+
+
+def test_full_size_pack_matches_independent_gpu_slicing():
+    """BASELINE size (10 M particles): compare against torch's own strided copy on the GPU
+    (an independent implementation), bit for bit, plus a checksum of checksums."""
+    N = 10_000_000
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
+    vel = torch.randn((N, 4), generator=g, device="cuda")
+    tid = torch.randperm(N, generator=g, device="cuda").to(torch.int32)
+    o_pos = torch.empty((N, 3), dtype=torch.float32, device="cuda")
+    o_vel = torch.empty((N, 3), dtype=torch.float32, device="cuda")
+    o_tid = torch.empty((N,), dtype=torch.int32, device="cuda")
+    G.hip_pack([(o_pos, np.float32, 3, pos, 0, None, False), (o_vel, np.float32, 3, vel, 0, None, False),
+                (o_tid, np.uint32, 1, tid.view(N, 1), 0, None, False)], N)
+    assert torch.equal(o_pos.view(torch.int32), pos[:, :3].contiguous().view(torch.int32))
+    assert torch.equal(o_vel.view(torch.int32), vel[:, :3].contiguous().view(torch.int32))
+    assert torch.equal(o_tid, tid)
+    # idempotence: packing the packed chunk with stride == M is the identity
+    again = torch.empty_like(o_pos)
+    G.hip_pack([(again, np.float32, 3, o_pos, 0, None, False)], N)
+    assert torch.equal(again.view(torch.int32), o_pos.view(torch.int32))
+    assert int(o_tid.to(torch.int64).sum().item()) == N * (N - 1) // 2
