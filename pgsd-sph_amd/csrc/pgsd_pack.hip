@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace pgsd_amd
@@ -106,19 +107,19 @@ template<int SSZ, int DSZ> __device__ __forceinline__ uint64_t convert_elem(uint
 
 // Stream the re-packed tile of one output chunk from LDS to global memory:
 // 16 bytes per lane per store, lanes consecutive => each wave store covers 1 KiB.
-template<int SSZ, int DSZ>
+template<int SSZ, int DSZ, int NT, int KIND = -1>
 __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uint32_t rows,
-                                          uint32_t stride_elems, uint64_t row0)
+                                          uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
     constexpr uint32_t EPT = 16 / DSZ; // elements per 16-byte vector
     const uint32_t M = o.M;
     const uint32_t nelem = rows * M;
     const uint32_t nvec = nelem / EPT;
     char* gdst = (char*)o.dst + row0 * (uint64_t)M * DSZ;
-    const uint32_t kind = o.kind;
+    const uint32_t kind = KIND >= 0 ? (uint32_t)KIND : o.kind;
     const uint32_t col0 = o.col0;
 
-    for (uint32_t v = threadIdx.x; v < nvec; v += PACK_THREADS)
+    for (uint32_t v = tid; v < nvec; v += NT)
         {
         uint32_t e = v * EPT;
         // row = e / M via multiply-high (exact for e < 2^32 / M, host guarantees it)
@@ -151,7 +152,7 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
         __builtin_nontemporal_store(out, (u32x4*)(gdst + (size_t)v * 16));
         }
     // ragged end of the last tile: element-wise
-    for (uint32_t e = nvec * EPT + threadIdx.x; e < nelem; e += PACK_THREADS)
+    for (uint32_t e = nvec * EPT + tid; e < nelem; e += NT)
         {
         uint32_t row = (M == 1) ? e : __umulhi(e, o.magic);
         uint32_t col = e - row * M;
@@ -169,21 +170,116 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
         }
     }
 
-template<int SSZ>
+template<int SSZ, int NT>
 __device__ __forceinline__ void emit_dispatch(const PackOut& o, const char* lds, uint32_t rows,
-                                              uint32_t stride_elems, uint64_t row0)
+                                              uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
     switch (o.dsz)
         {
-        case 1: emit_tile<SSZ, 1>(o, lds, rows, stride_elems, row0); break;
-        case 2: emit_tile<SSZ, 2>(o, lds, rows, stride_elems, row0); break;
-        case 4: emit_tile<SSZ, 4>(o, lds, rows, stride_elems, row0); break;
-        default: emit_tile<SSZ, 8>(o, lds, rows, stride_elems, row0); break;
+        case 1: emit_tile<SSZ, 1, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        case 2: emit_tile<SSZ, 2, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        case 4: emit_tile<SSZ, 4, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        default: emit_tile<SSZ, 8, NT>(o, lds, rows, stride_elems, row0, tid); break;
         }
     }
 
-// Fused multi-field pack.  One workgroup owns a tile of `tile_rows` particles at a time and
-// walks all source groups for it.
+template<int NT, int MODE = PACK_MODE_GENERIC>
+__device__ __forceinline__ void emit_group(const PackGroup& g, const char* lds, uint32_t rows, uint64_t row0,
+                                           uint32_t tid)
+    {
+    for (uint32_t oi = 0; oi < g.n_out; oi++)
+        {
+        const PackOut& o = g.out[oi];
+        if constexpr (MODE == PACK_MODE_W32)
+            {
+            // 32-bit words moved unchanged (float4 -> N x 3 float, typeid in position.w, int3 images)
+            emit_tile<4, 4, NT, PACK_BITS>(o, lds, rows, g.stride, row0, tid);
+            continue;
+            }
+        if constexpr (MODE == PACK_MODE_F64_F32)
+            {
+            // double4 / double sources written as float32 chunks
+            emit_tile<8, 4, NT, PACK_F2F>(o, lds, rows, g.stride, row0, tid);
+            continue;
+            }
+        switch (g.ssz)
+            {
+            case 1: emit_dispatch<1, NT>(o, lds, rows, g.stride, row0, tid); break;
+            case 2: emit_dispatch<2, NT>(o, lds, rows, g.stride, row0, tid); break;
+            case 4: emit_dispatch<4, NT>(o, lds, rows, g.stride, row0, tid); break;
+            default: emit_dispatch<8, NT>(o, lds, rows, g.stride, row0, tid); break;
+            }
+        }
+    }
+
+// Bring `rows` source rows starting at row0 into LDS with NT cooperating lanes:
+// a linear 16-byte-per-lane stream, or a row gather through `order`.
+template<int NT>
+__device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32_t rows, uint64_t row0, uint32_t tid)
+    {
+    const uint32_t rowbytes = g.rowbytes;
+    if (g.order == nullptr)
+        {
+        // rows*rowbytes contiguous bytes, 16-byte aligned start
+        const char* gsrc = (const char*)g.src + row0 * rowbytes;
+        const uint32_t nbytes = rows * rowbytes;
+        const uint32_t nvec = nbytes >> 4;
+        uint32_t v = tid;
+        // four independent 16-byte loads in flight per lane
+        for (; v + 3 * NT < nvec; v += 4 * NT)
+            {
+            u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+            u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + NT);
+            u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * NT);
+            u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * NT);
+            ((u32x4*)lds)[v] = a;
+            ((u32x4*)lds)[v + NT] = b;
+            ((u32x4*)lds)[v + 2 * NT] = c;
+            ((u32x4*)lds)[v + 3 * NT] = d;
+            }
+        for (; v < nvec; v += NT)
+            ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+        for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += NT)
+            lds[b] = gsrc[b];
+        }
+    else
+        {
+        // row i of the tile comes from source row order[row0 + i]
+        const uint32_t* ord = g.order + row0;
+        if (rowbytes == 16)
+            {
+            for (uint32_t i = tid; i < rows; i += NT)
+                ((u32x4*)lds)[i] = *((const u32x4*)g.src + ord[i]);
+            }
+        else if (rowbytes == 32)
+            {
+            for (uint32_t i = tid; i < 2 * rows; i += NT)
+                ((u32x4*)lds)[i] = *((const u32x4*)g.src + 2 * (uint64_t)ord[i >> 1] + (i & 1));
+            }
+        else if ((rowbytes & 3) == 0)
+            {
+            const uint32_t wpr = rowbytes >> 2;
+            const uint32_t nw = rows * wpr;
+            for (uint32_t i = tid; i < nw; i += NT)
+                {
+                uint32_t r = i / wpr, c = i - r * wpr;
+                ((uint32_t*)lds)[i] = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
+                }
+            }
+        else
+            {
+            const uint32_t nb = rows * rowbytes;
+            for (uint32_t i = tid; i < nb; i += NT)
+                {
+                uint32_t r = i / rowbytes, c = i - r * rowbytes;
+                lds[i] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
+                }
+            }
+        }
+    }
+
+// Fused multi-field pack, workgroup-tiled variant (wide rows): one workgroup owns a tile of
+// `tile_rows` particles at a time and walks all source groups for it.
 __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
     {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -194,84 +290,85 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs
         {
         const uint64_t row0 = tile * TILE;
         const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
-
         for (uint32_t gi = 0; gi < args.n_groups; gi++)
             {
             const PackGroup& g = args.g[gi];
-            const uint32_t rowbytes = g.rowbytes;
-
-            if (g.order == nullptr)
-                {
-                // linear tile: rows*rowbytes contiguous bytes, 16-byte aligned start
-                const char* gsrc = (const char*)g.src + row0 * rowbytes;
-                const uint32_t nbytes = rows * rowbytes;
-                const uint32_t nvec = nbytes >> 4;
-                uint32_t v = tid;
-                // four independent 16-byte loads in flight per lane
-                for (; v + 3 * PACK_THREADS < nvec; v += 4 * PACK_THREADS)
-                    {
-                    u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-                    u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + PACK_THREADS);
-                    u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * PACK_THREADS);
-                    u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * PACK_THREADS);
-                    ((u32x4*)lds)[v] = a;
-                    ((u32x4*)lds)[v + PACK_THREADS] = b;
-                    ((u32x4*)lds)[v + 2 * PACK_THREADS] = c;
-                    ((u32x4*)lds)[v + 3 * PACK_THREADS] = d;
-                    }
-                for (; v < nvec; v += PACK_THREADS)
-                    ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-                for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
-                    lds[b] = gsrc[b];
-                }
-            else
-                {
-                // gathered tile: row i of the tile comes from source row order[row0 + i]
-                const uint32_t* ord = g.order + row0;
-                if (rowbytes == 16)
-                    {
-                    for (uint32_t i = tid; i < rows; i += PACK_THREADS)
-                        ((u32x4*)lds)[i] = *((const u32x4*)g.src + ord[i]);
-                    }
-                else if (rowbytes == 32)
-                    {
-                    for (uint32_t i = tid; i < 2 * rows; i += PACK_THREADS)
-                        ((u32x4*)lds)[i] = *((const u32x4*)g.src + 2 * (uint64_t)ord[i >> 1] + (i & 1));
-                    }
-                else if ((rowbytes & 3) == 0)
-                    {
-                    const uint32_t wpr = rowbytes >> 2;
-                    const uint32_t nw = rows * wpr;
-                    for (uint32_t i = tid; i < nw; i += PACK_THREADS)
-                        {
-                        uint32_t r = i / wpr, c = i - r * wpr;
-                        ((uint32_t*)lds)[i] = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
-                        }
-                    }
-                else
-                    {
-                    const uint32_t nb = rows * rowbytes;
-                    for (uint32_t i = tid; i < nb; i += PACK_THREADS)
-                        {
-                        uint32_t r = i / rowbytes, c = i - r * rowbytes;
-                        lds[i] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
-                        }
-                    }
-                }
+            stage_rows<PACK_THREADS>(g, lds, rows, row0, tid);
             __syncthreads();
-
-            for (uint32_t oi = 0; oi < g.n_out; oi++)
-                {
-                const PackOut& o = g.out[oi];
-                switch (g.ssz)
-                    {
-                    case 1: emit_dispatch<1>(o, lds, rows, g.stride, row0); break;
-                    case 2: emit_dispatch<2>(o, lds, rows, g.stride, row0); break;
-                    case 4: emit_dispatch<4>(o, lds, rows, g.stride, row0); break;
-                    default: emit_dispatch<8>(o, lds, rows, g.stride, row0); break;
-                    }
-                }
+            emit_group<PACK_THREADS>(g, lds, rows, row0, tid);
             __syncthreads();
+            }
+        }
+    }
+
+// Fused multi-field pack, wave-streaming variant (the hot path).
+//
+// Every 64-lane wavefront is an independent streaming engine: it owns a contiguous,
+// balanced range of particles and a private PACK_WAVE_LDS-byte LDS window; per step it
+// streams `wave_rows` source rows (<= 4 KiB, 16 B per lane per load, four loads in
+// flight) into its window, re-packs / converts out of it and streams the chunk rows out
+// (16 B per lane per store).  No workgroup barrier exists anywhere: LDS operations of one
+// wave execute in program order, so the only synchronisation is the compiler-level wave
+// barrier between the window's writes and reads.  Waves therefore never wait for each
+// other, and 32 waves per CU keep ~128 KiB of loads in flight per CU.
+// Dense same-type fields (stride == M) bypass LDS altogether.
+template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_waves_kernel(const PackArgs args)
+    {
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    char* lds = lds_all + wave * PACK_WAVE_LDS;
+
+    // balanced contiguous range of 16-row units for this wave (16 rows keep every tile
+    // start 16-byte aligned in the source and in every chunk)
+    const uint64_t gw = (uint64_t)blockIdx.x * (PACK_THREADS / 64) + wave;
+    const uint64_t nw = (uint64_t)gridDim.x * (PACK_THREADS / 64);
+    const uint64_t units = (args.N + 15) >> 4;
+    const uint64_t r_lo = (units * gw / nw) << 4;
+    uint64_t r_hi = (units * (gw + 1) / nw) << 4;
+    if (r_hi > args.N)
+        r_hi = args.N;
+
+    for (uint32_t gi = 0; gi < args.n_groups; gi++)
+        {
+        const PackGroup& g = args.g[gi];
+        if (g.direct)
+            {
+            // dense copy: chunk bytes == source bytes
+            const char* gsrc = (const char*)g.src + r_lo * g.rowbytes;
+            char* gdst = (char*)g.out[0].dst + r_lo * g.rowbytes;
+            const uint64_t nbytes = (r_hi > r_lo ? r_hi - r_lo : 0) * g.rowbytes;
+            const uint64_t nvec = nbytes >> 4;
+            uint64_t v = lane;
+            for (; v + 3 * 64 < nvec; v += 4 * 64)
+                {
+                u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+                u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + 64);
+                u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 128);
+                u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 192);
+                __builtin_nontemporal_store(a, (u32x4*)gdst + v);
+                __builtin_nontemporal_store(b, (u32x4*)gdst + v + 64);
+                __builtin_nontemporal_store(c, (u32x4*)gdst + v + 128);
+                __builtin_nontemporal_store(d, (u32x4*)gdst + v + 192);
+                }
+            for (; v < nvec; v += 64)
+                __builtin_nontemporal_store(__builtin_nontemporal_load((const u32x4*)gsrc + v), (u32x4*)gdst + v);
+            for (uint64_t b = (nvec << 4) + lane; b < nbytes; b += 64)
+                gdst[b] = gsrc[b];
+            continue;
+            }
+        const uint32_t W = g.wave_rows;
+        for (uint64_t row0 = r_lo; row0 < r_hi; row0 += W)
+            {
+            const uint32_t rows = (uint32_t)((r_hi - row0 < (uint64_t)W) ? r_hi - row0 : W);
+            stage_rows<64>(g, lds, rows, row0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            emit_group<64, MODE>(g, lds, rows, row0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
@@ -530,12 +627,22 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         args.N = N;
         uint32_t max_rowbytes = 0;
         bool any = false;
+        int mode = -1; // a launch holds jobs of one specialisation only
         for (uint32_t i = next; i < n_jobs; i++)
             {
             if (done[i])
                 continue;
             const pgsd_pack_job& j = jobs[i];
             const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type);
+            const uint32_t jdsz = (uint32_t)sizeof_type(j.dst_type);
+            const uint32_t jkind = conv_kind(j.src.src_type, j.dst_type, j.src.bitcast);
+            const int jmode = (ssz == 4 && jdsz == 4 && jkind == PACK_BITS)  ? PACK_MODE_W32
+                              : (ssz == 8 && jdsz == 4 && jkind == PACK_F2F) ? PACK_MODE_F64_F32
+                                                                             : PACK_MODE_GENERIC;
+            if (mode < 0)
+                mode = jmode;
+            else if (mode != jmode)
+                continue; // next batch
             // find a group with the same source
             int gi = -1;
             for (uint32_t k = 0; k < args.n_groups; k++)
@@ -569,20 +676,59 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         if (!any)
             break;
-        // tile: as many rows as fit PACK_LDS_BYTES, power of two in [16, 1024]
-        uint32_t tile = 1024;
-        while (tile > 16 && (uint64_t)tile * max_rowbytes > PACK_LDS_BYTES)
-            tile >>= 1;
-        args.tile_rows = tile;
-        args.n_tiles = (N + tile - 1) / tile;
-        uint64_t blocks = args.n_tiles;
-        uint64_t cap = (uint64_t)num_cus() * 8;
-        if (blocks > cap)
-            blocks = cap;
-        size_t lds_bytes = (size_t)tile * max_rowbytes;
-        lds_bytes = (lds_bytes + 15) & ~(size_t)15;
-        hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream,
-                           args);
+        // wave-streaming kernel unless a source row is too wide for a wave's LDS window
+        bool use_waves = max_rowbytes * 16 <= PACK_WAVE_LDS;
+        if (const char* e = getenv("PGSD_PACK_KERNEL"))
+            use_waves = use_waves && strcmp(e, "tiles") != 0;
+        uint64_t per_cu = 8;
+        if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
+            per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
+        if (use_waves)
+            {
+            for (uint32_t k = 0; k < args.n_groups; k++)
+                {
+                PackGroup& g = args.g[k];
+                uint32_t w = (PACK_WAVE_LDS / g.rowbytes) & ~15u;
+                g.wave_rows = w > 1024 ? 1024 : w;
+                const PackOut& o = g.out[0];
+                g.direct = (g.n_out == 1 && g.order == nullptr && o.M == g.stride && o.col0 == 0
+                            && o.kind == PACK_BITS && o.dsz == g.ssz)
+                               ? 1u
+                               : 0u;
+                }
+            // one wave needs at least one 64-row step to be worth launching
+            uint64_t blocks = (uint64_t)num_cus() * per_cu;
+            uint64_t max_blocks = (N + 255) / 256;
+            if (blocks > max_blocks)
+                blocks = max_blocks;
+            const size_t wave_lds = (PACK_THREADS / 64) * PACK_WAVE_LDS;
+            if (mode == PACK_MODE_W32)
+                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_W32>, dim3((unsigned)blocks), dim3(PACK_THREADS),
+                                   wave_lds, stream, args);
+            else if (mode == PACK_MODE_F64_F32)
+                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_F64_F32>, dim3((unsigned)blocks),
+                                   dim3(PACK_THREADS), wave_lds, stream, args);
+            else
+                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_GENERIC>, dim3((unsigned)blocks),
+                                   dim3(PACK_THREADS), wave_lds, stream, args);
+            }
+        else
+            {
+            // tile: as many rows as fit PACK_LDS_BYTES, power of two in [16, 1024]
+            uint32_t tile = 1024;
+            while (tile > 16 && (uint64_t)tile * max_rowbytes > PACK_LDS_BYTES)
+                tile >>= 1;
+            args.tile_rows = tile;
+            args.n_tiles = (N + tile - 1) / tile;
+            uint64_t blocks = args.n_tiles;
+            uint64_t cap = (uint64_t)num_cus() * per_cu;
+            if (blocks > cap)
+                blocks = cap;
+            size_t lds_bytes = (size_t)tile * max_rowbytes;
+            lds_bytes = (lds_bytes + 15) & ~(size_t)15;
+            hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream,
+                               args);
+            }
         while (next < n_jobs && done[next])
             next++;
         if (next == n_jobs)

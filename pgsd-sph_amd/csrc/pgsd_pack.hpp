@@ -16,7 +16,8 @@ enum
     {
     PACK_MAX_GROUPS = 8,       // distinct source arrays per launch
     PACK_MAX_OUT = 6,          // chunks fed from one source array
-    PACK_LDS_BYTES = 32768,    // LDS tile budget per workgroup (>= 5 workgroups per CU)
+    PACK_LDS_BYTES = 32768,    // LDS tile budget per workgroup of the workgroup-tiled kernel
+    PACK_WAVE_LDS = 4096,      // private LDS window of one wavefront in the wave-streaming kernel
     PACK_MAX_ROWBYTES = 2048,  // wider source rows take the generic kernel
     PACK_MAX_M = 1024
     };
@@ -29,6 +30,14 @@ enum
     PACK_F2F = 2,  // f64 -> f32 (round to nearest even) or f32 -> f64
     PACK_U2F = 3,  // unsigned integer (<= 32 bit) -> f32 / f64
     PACK_S2F = 4   // signed integer (<= 32 bit) -> f32 / f64
+    };
+
+// compile-time specialisations of the wave-streaming kernel
+enum
+    {
+    PACK_MODE_GENERIC = 0, // any element sizes / conversions, decided at run time per output
+    PACK_MODE_W32 = 1,     // 4-byte source and chunk elements, bits unchanged
+    PACK_MODE_F64_F32 = 2  // f64 sources, f32 chunks
     };
 
 struct PackOut
@@ -50,6 +59,8 @@ struct PackGroup
     uint32_t ssz;          // bytes per source element
     uint32_t stride;       // elements per source row
     uint32_t n_out;
+    uint32_t wave_rows;    // rows per step of one wave (multiple of 16, wave_rows*rowbytes <= PACK_WAVE_LDS)
+    uint32_t direct;       // 1: single dense same-type output, chunk bytes == source bytes
     PackOut out[PACK_MAX_OUT];
     };
 
