@@ -105,9 +105,33 @@ template<int SSZ, int DSZ> __device__ __forceinline__ uint64_t convert_elem(uint
         }
     }
 
+// Variant bits of the streaming kernels (compile-time; the launcher picks one instantiation).
+enum
+    {
+    VAR_GLDS = 1,       // stage linear tiles with LDS-DMA (global_load_lds_dwordx4) instead of VGPRs
+    VAR_PLAIN_LOAD = 2, // default cache policy for source loads instead of non-temporal
+    VAR_PLAIN_STORE = 4 // default cache policy for chunk stores instead of non-temporal
+    };
+
+template<int VAR> __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+    {
+    if constexpr (VAR & VAR_PLAIN_LOAD)
+        return *p;
+    else
+        return __builtin_nontemporal_load(p);
+    }
+
+template<int VAR> __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p)
+    {
+    if constexpr (VAR & VAR_PLAIN_STORE)
+        *p = v;
+    else
+        __builtin_nontemporal_store(v, p);
+    }
+
 // Stream the re-packed tile of one output chunk from LDS to global memory:
 // 16 bytes per lane per store, lanes consecutive => each wave store covers 1 KiB.
-template<int SSZ, int DSZ, int NT, int KIND = -1>
+template<int SSZ, int DSZ, int NT, int VAR, int KIND = -1>
 __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uint32_t rows,
                                           uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
@@ -149,7 +173,7 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
                 }
             }
         u32x4 out = {w[0], w[1], w[2], w[3]};
-        __builtin_nontemporal_store(out, (u32x4*)(gdst + (size_t)v * 16));
+        stream_store<VAR>(out, (u32x4*)(gdst + (size_t)v * 16));
         }
     // ragged end of the last tile: element-wise
     for (uint32_t e = nvec * EPT + tid; e < nelem; e += NT)
@@ -170,20 +194,20 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
         }
     }
 
-template<int SSZ, int NT>
+template<int SSZ, int NT, int VAR>
 __device__ __forceinline__ void emit_dispatch(const PackOut& o, const char* lds, uint32_t rows,
                                               uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
     switch (o.dsz)
         {
-        case 1: emit_tile<SSZ, 1, NT>(o, lds, rows, stride_elems, row0, tid); break;
-        case 2: emit_tile<SSZ, 2, NT>(o, lds, rows, stride_elems, row0, tid); break;
-        case 4: emit_tile<SSZ, 4, NT>(o, lds, rows, stride_elems, row0, tid); break;
-        default: emit_tile<SSZ, 8, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        case 1: emit_tile<SSZ, 1, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
+        case 2: emit_tile<SSZ, 2, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
+        case 4: emit_tile<SSZ, 4, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
+        default: emit_tile<SSZ, 8, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
         }
     }
 
-template<int NT, int MODE = PACK_MODE_GENERIC>
+template<int NT, int MODE, int VAR>
 __device__ __forceinline__ void emit_group(const PackGroup& g, const char* lds, uint32_t rows, uint64_t row0,
                                            uint32_t tid)
     {
@@ -193,28 +217,28 @@ __device__ __forceinline__ void emit_group(const PackGroup& g, const char* lds, 
         if constexpr (MODE == PACK_MODE_W32)
             {
             // 32-bit words moved unchanged (float4 -> N x 3 float, typeid in position.w, int3 images)
-            emit_tile<4, 4, NT, PACK_BITS>(o, lds, rows, g.stride, row0, tid);
+            emit_tile<4, 4, NT, VAR, PACK_BITS>(o, lds, rows, g.stride, row0, tid);
             continue;
             }
         if constexpr (MODE == PACK_MODE_F64_F32)
             {
             // double4 / double sources written as float32 chunks
-            emit_tile<8, 4, NT, PACK_F2F>(o, lds, rows, g.stride, row0, tid);
+            emit_tile<8, 4, NT, VAR, PACK_F2F>(o, lds, rows, g.stride, row0, tid);
             continue;
             }
         switch (g.ssz)
             {
-            case 1: emit_dispatch<1, NT>(o, lds, rows, g.stride, row0, tid); break;
-            case 2: emit_dispatch<2, NT>(o, lds, rows, g.stride, row0, tid); break;
-            case 4: emit_dispatch<4, NT>(o, lds, rows, g.stride, row0, tid); break;
-            default: emit_dispatch<8, NT>(o, lds, rows, g.stride, row0, tid); break;
+            case 1: emit_dispatch<1, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
+            case 2: emit_dispatch<2, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
+            case 4: emit_dispatch<4, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
+            default: emit_dispatch<8, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
             }
         }
     }
 
 // Bring `rows` source rows starting at row0 into LDS with NT cooperating lanes:
 // a linear 16-byte-per-lane stream, or a row gather through `order`.
-template<int NT>
+template<int NT, int VAR>
 __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32_t rows, uint64_t row0, uint32_t tid)
     {
     const uint32_t rowbytes = g.rowbytes;
@@ -224,21 +248,39 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
         const char* gsrc = (const char*)g.src + row0 * rowbytes;
         const uint32_t nbytes = rows * rowbytes;
         const uint32_t nvec = nbytes >> 4;
-        uint32_t v = tid;
-        // four independent 16-byte loads in flight per lane
-        for (; v + 3 * NT < nvec; v += 4 * NT)
+        if constexpr (VAR & VAR_GLDS)
             {
-            u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-            u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + NT);
-            u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * NT);
-            u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * NT);
-            ((u32x4*)lds)[v] = a;
-            ((u32x4*)lds)[v + NT] = b;
-            ((u32x4*)lds)[v + 2 * NT] = c;
-            ((u32x4*)lds)[v + 3 * NT] = d;
+            // LDS-DMA: the 16 bytes of lane l land at (wave-uniform LDS base) + 16*l, so a
+            // linear tile needs no VGPR round trip; the workgroup barrier that follows drains it
+            const uint32_t wave_first = tid & ~63u;
+            for (uint32_t v0 = 0; v0 < nvec; v0 += NT)
+                {
+                const uint32_t v = v0 + tid;
+                if (v < nvec)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)((const u32x4*)gsrc + v),
+                        (__attribute__((address_space(3))) void*)(lds + (size_t)(v0 + wave_first) * 16), 16, 0,
+                        (VAR & VAR_PLAIN_LOAD) ? 0 : 2);
+                }
             }
-        for (; v < nvec; v += NT)
-            ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+        else
+            {
+            uint32_t v = tid;
+            // four independent 16-byte loads in flight per lane
+            for (; v + 3 * NT < nvec; v += 4 * NT)
+                {
+                u32x4 a = stream_load<VAR>((const u32x4*)gsrc + v);
+                u32x4 b = stream_load<VAR>((const u32x4*)gsrc + v + NT);
+                u32x4 c = stream_load<VAR>((const u32x4*)gsrc + v + 2 * NT);
+                u32x4 d = stream_load<VAR>((const u32x4*)gsrc + v + 3 * NT);
+                ((u32x4*)lds)[v] = a;
+                ((u32x4*)lds)[v + NT] = b;
+                ((u32x4*)lds)[v + 2 * NT] = c;
+                ((u32x4*)lds)[v + 3 * NT] = d;
+                }
+            for (; v < nvec; v += NT)
+                ((u32x4*)lds)[v] = stream_load<VAR>((const u32x4*)gsrc + v);
+            }
         for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += NT)
             lds[b] = gsrc[b];
         }
@@ -278,9 +320,12 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
         }
     }
 
-// Fused multi-field pack, workgroup-tiled variant (wide rows): one workgroup owns a tile of
-// `tile_rows` particles at a time and walks all source groups for it.
-__global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
+// Fused multi-field pack, workgroup-tiled kernel.  One 256-thread workgroup (four 64-lane
+// wavefronts) owns a tile of `tile_rows` particles at a time; tiles are dealt to
+// workgroups round-robin, so the workgroups resident at any moment stream one contiguous
+// window of every array (DRAM-page friendly).  Per tile and source group: stage -> barrier
+// -> emit every chunk fed by that source -> barrier.
+template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
     {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t tid = threadIdx.x;
@@ -293,79 +338,66 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs
         for (uint32_t gi = 0; gi < args.n_groups; gi++)
             {
             const PackGroup& g = args.g[gi];
-            stage_rows<PACK_THREADS>(g, lds, rows, row0, tid);
+            stage_rows<PACK_THREADS, VAR>(g, lds, rows, row0, tid);
             __syncthreads();
-            emit_group<PACK_THREADS>(g, lds, rows, row0, tid);
+            emit_group<PACK_THREADS, MODE, VAR>(g, lds, rows, row0, tid);
             __syncthreads();
             }
         }
     }
 
-// Fused multi-field pack, wave-streaming variant (the hot path).
-//
-// Every 64-lane wavefront is an independent streaming engine: it owns a contiguous,
-// balanced range of particles and a private PACK_WAVE_LDS-byte LDS window; per step it
-// streams `wave_rows` source rows (<= 4 KiB, 16 B per lane per load, four loads in
-// flight) into its window, re-packs / converts out of it and streams the chunk rows out
-// (16 B per lane per store).  No workgroup barrier exists anywhere: LDS operations of one
-// wave execute in program order, so the only synchronisation is the compiler-level wave
-// barrier between the window's writes and reads.  Waves therefore never wait for each
-// other, and 32 waves per CU keep ~128 KiB of loads in flight per CU.
-// Dense same-type fields (stride == M) bypass LDS altogether.
-template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_waves_kernel(const PackArgs args)
+// Wave-streaming kernel: every 64-lane wavefront owns a private PACK_WAVE_LDS-byte LDS
+// window and steps through `wave_rows`-row pieces dealt round-robin over all waves of the
+// grid; no workgroup barrier exists (LDS operations of one wave execute in program
+// order), so waves never wait for each other.  Dense same-type fields bypass LDS.
+template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack_waves_kernel(const PackArgs args)
     {
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     char* lds = lds_all + wave * PACK_WAVE_LDS;
-
-    // balanced contiguous range of 16-row units for this wave (16 rows keep every tile
-    // start 16-byte aligned in the source and in every chunk)
     const uint64_t gw = (uint64_t)blockIdx.x * (PACK_THREADS / 64) + wave;
     const uint64_t nw = (uint64_t)gridDim.x * (PACK_THREADS / 64);
-    const uint64_t units = (args.N + 15) >> 4;
-    const uint64_t r_lo = (units * gw / nw) << 4;
-    uint64_t r_hi = (units * (gw + 1) / nw) << 4;
-    if (r_hi > args.N)
-        r_hi = args.N;
 
     for (uint32_t gi = 0; gi < args.n_groups; gi++)
         {
         const PackGroup& g = args.g[gi];
-        if (g.direct)
-            {
-            // dense copy: chunk bytes == source bytes
-            const char* gsrc = (const char*)g.src + r_lo * g.rowbytes;
-            char* gdst = (char*)g.out[0].dst + r_lo * g.rowbytes;
-            const uint64_t nbytes = (r_hi > r_lo ? r_hi - r_lo : 0) * g.rowbytes;
-            const uint64_t nvec = nbytes >> 4;
-            uint64_t v = lane;
-            for (; v + 3 * 64 < nvec; v += 4 * 64)
-                {
-                u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-                u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + 64);
-                u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 128);
-                u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 192);
-                __builtin_nontemporal_store(a, (u32x4*)gdst + v);
-                __builtin_nontemporal_store(b, (u32x4*)gdst + v + 64);
-                __builtin_nontemporal_store(c, (u32x4*)gdst + v + 128);
-                __builtin_nontemporal_store(d, (u32x4*)gdst + v + 192);
-                }
-            for (; v < nvec; v += 64)
-                __builtin_nontemporal_store(__builtin_nontemporal_load((const u32x4*)gsrc + v), (u32x4*)gdst + v);
-            for (uint64_t b = (nvec << 4) + lane; b < nbytes; b += 64)
-                gdst[b] = gsrc[b];
-            continue;
-            }
         const uint32_t W = g.wave_rows;
-        for (uint64_t row0 = r_lo; row0 < r_hi; row0 += W)
+        const uint64_t n_steps = (args.N + W - 1) / W;
+        for (uint64_t step = gw; step < n_steps; step += nw)
             {
-            const uint32_t rows = (uint32_t)((r_hi - row0 < (uint64_t)W) ? r_hi - row0 : W);
-            stage_rows<64>(g, lds, rows, row0, lane);
+            const uint64_t row0 = step * W;
+            const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)W) ? args.N - row0 : W);
+            if (g.direct)
+                {
+                // dense copy: chunk bytes == source bytes
+                const char* gsrc = (const char*)g.src + row0 * g.rowbytes;
+                char* gdst = (char*)g.out[0].dst + row0 * g.rowbytes;
+                const uint32_t nbytes = rows * g.rowbytes;
+                const uint32_t nvec = nbytes >> 4;
+                uint32_t v = lane;
+                for (; v + 3 * 64 < nvec; v += 4 * 64)
+                    {
+                    u32x4 a = stream_load<VAR>((const u32x4*)gsrc + v);
+                    u32x4 b = stream_load<VAR>((const u32x4*)gsrc + v + 64);
+                    u32x4 c = stream_load<VAR>((const u32x4*)gsrc + v + 128);
+                    u32x4 d = stream_load<VAR>((const u32x4*)gsrc + v + 192);
+                    stream_store<VAR>(a, (u32x4*)gdst + v);
+                    stream_store<VAR>(b, (u32x4*)gdst + v + 64);
+                    stream_store<VAR>(c, (u32x4*)gdst + v + 128);
+                    stream_store<VAR>(d, (u32x4*)gdst + v + 192);
+                    }
+                for (; v < nvec; v += 64)
+                    stream_store<VAR>(stream_load<VAR>((const u32x4*)gsrc + v), (u32x4*)gdst + v);
+                for (uint32_t b = (nvec << 4) + lane; b < nbytes; b += 64)
+                    gdst[b] = gsrc[b];
+                continue;
+                }
+            stage_rows<64, VAR & ~VAR_GLDS>(g, lds, rows, row0, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            emit_group<64, MODE>(g, lds, rows, row0, lane);
+            emit_group<64, MODE, VAR>(g, lds, rows, row0, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -574,6 +606,44 @@ static int num_cus()
     return g_num_cus;
     }
 
+template<int MODE, int VAR>
+static void launch_one(bool waves, unsigned blocks, size_t lds_bytes, hipStream_t stream, const PackArgs& args)
+    {
+    if (waves)
+        hipLaunchKernelGGL((pack_waves_kernel<MODE, VAR & ~VAR_GLDS>), dim3(blocks), dim3(PACK_THREADS), lds_bytes,
+                           stream, args);
+    else
+        hipLaunchKernelGGL((pack_tiles_kernel<MODE, VAR>), dim3(blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+    }
+
+template<int MODE>
+static void launch_mode(bool waves, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
+                        const PackArgs& args)
+    {
+    switch (var & 7)
+        {
+        case 0: launch_one<MODE, 0>(waves, blocks, lds_bytes, stream, args); break;
+        case 1: launch_one<MODE, 1>(waves, blocks, lds_bytes, stream, args); break;
+        case 2: launch_one<MODE, 2>(waves, blocks, lds_bytes, stream, args); break;
+        case 3: launch_one<MODE, 3>(waves, blocks, lds_bytes, stream, args); break;
+        case 4: launch_one<MODE, 4>(waves, blocks, lds_bytes, stream, args); break;
+        case 5: launch_one<MODE, 5>(waves, blocks, lds_bytes, stream, args); break;
+        case 6: launch_one<MODE, 6>(waves, blocks, lds_bytes, stream, args); break;
+        default: launch_one<MODE, 7>(waves, blocks, lds_bytes, stream, args); break;
+        }
+    }
+
+static void launch_variant(bool waves, int mode, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
+                           const PackArgs& args)
+    {
+    if (mode == PACK_MODE_W32)
+        launch_mode<PACK_MODE_W32>(waves, var, blocks, lds_bytes, stream, args);
+    else if (mode == PACK_MODE_F64_F32)
+        launch_mode<PACK_MODE_F64_F32>(waves, var, blocks, lds_bytes, stream, args);
+    else
+        launch_mode<PACK_MODE_GENERIC>(waves, (var & VAR_GLDS), blocks, lds_bytes, stream, args);
+    }
+
 int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
     {
     if (n_jobs == 0 || N == 0)
@@ -676,13 +746,22 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         if (!any)
             break;
-        // wave-streaming kernel unless a source row is too wide for a wave's LDS window
-        bool use_waves = max_rowbytes * 16 <= PACK_WAVE_LDS;
+        // kernel choice (defaults from measurements on MI355X, profiles/; env overrides are
+        // for the tuning sweeps of tools/pack_bench.py)
+        bool use_waves = false;
+        uint64_t per_cu = 4;
+        int var = 0;
+        uint32_t tile_cap = 1024;
         if (const char* e = getenv("PGSD_PACK_KERNEL"))
-            use_waves = use_waves && strcmp(e, "tiles") != 0;
-        uint64_t per_cu = 8;
+            use_waves = strcmp(e, "waves") == 0;
         if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
             per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
+        if (const char* e = getenv("PGSD_PACK_VARIANT"))
+            var = atoi(e) & 7;
+        if (const char* e = getenv("PGSD_PACK_TILE"))
+            tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
+        if (max_rowbytes * 16 > PACK_WAVE_LDS)
+            use_waves = false; // a source row too wide for a wave's LDS window
         if (use_waves)
             {
             for (uint32_t k = 0; k < args.n_groups; k++)
@@ -696,28 +775,18 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                                ? 1u
                                : 0u;
                 }
-            // one wave needs at least one 64-row step to be worth launching
             uint64_t blocks = (uint64_t)num_cus() * per_cu;
             uint64_t max_blocks = (N + 255) / 256;
             if (blocks > max_blocks)
                 blocks = max_blocks;
-            const size_t wave_lds = (PACK_THREADS / 64) * PACK_WAVE_LDS;
-            if (mode == PACK_MODE_W32)
-                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_W32>, dim3((unsigned)blocks), dim3(PACK_THREADS),
-                                   wave_lds, stream, args);
-            else if (mode == PACK_MODE_F64_F32)
-                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_F64_F32>, dim3((unsigned)blocks),
-                                   dim3(PACK_THREADS), wave_lds, stream, args);
-            else
-                hipLaunchKernelGGL(pack_waves_kernel<PACK_MODE_GENERIC>, dim3((unsigned)blocks),
-                                   dim3(PACK_THREADS), wave_lds, stream, args);
+            launch_variant(true, mode, var, (unsigned)blocks, (PACK_THREADS / 64) * PACK_WAVE_LDS, stream, args);
             }
         else
             {
-            // tile: as many rows as fit PACK_LDS_BYTES, power of two in [16, 1024]
-            uint32_t tile = 1024;
-            while (tile > 16 && (uint64_t)tile * max_rowbytes > PACK_LDS_BYTES)
-                tile >>= 1;
+            // tile: as many rows as fit the LDS budget, power of two in [16, tile_cap]
+            uint32_t tile = 16;
+            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * max_rowbytes <= PACK_LDS_BYTES)
+                tile <<= 1;
             args.tile_rows = tile;
             args.n_tiles = (N + tile - 1) / tile;
             uint64_t blocks = args.n_tiles;
@@ -726,8 +795,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                 blocks = cap;
             size_t lds_bytes = (size_t)tile * max_rowbytes;
             lds_bytes = (lds_bytes + 15) & ~(size_t)15;
-            hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream,
-                               args);
+            launch_variant(false, mode, var, (unsigned)blocks, lds_bytes, stream, args);
             }
         while (next < n_jobs && done[next])
             next++;
