@@ -330,9 +330,9 @@ extern "C"
     struct pgsd_device_config
         {
         int device;             /* HIP device ordinal; -1 = current */
-        uint64_t slab_bytes;    /* pinned host staging slab size (default 32 MiB) */
-        uint32_t n_slabs;       /* slabs in the ring (default 8) */
-        uint32_t n_writers;     /* pwrite threads (default 8) */
+        uint64_t slab_bytes;    /* pinned host staging slab size (default 16 MiB) */
+        uint32_t n_slabs;       /* slabs in the ring (default 16) */
+        uint32_t n_writers;     /* pwrite threads (default 1: one file = one inode lock) */
         uint32_t profile;       /* 1 = bracket every pack launch with HIP events */
         uint32_t reserved;
         };

@@ -59,8 +59,10 @@ class DevicePipeline
             m_cfg.slab_bytes = (uint64_t)16 << 20;
         if (m_cfg.n_slabs == 0)
             m_cfg.n_slabs = 16;
+        // Buffered writes into ONE file serialise on its inode lock: a second writer thread
+        // halves the rate on tmpfs (profiles/r01_io_probes.md), so one writer is the default.
         if (m_cfg.n_writers == 0)
-            m_cfg.n_writers = 8;
+            m_cfg.n_writers = 1;
         HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
         m_slabs.resize(m_cfg.n_slabs);

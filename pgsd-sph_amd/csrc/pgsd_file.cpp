@@ -175,7 +175,7 @@ struct Impl
         {
         if (!pool)
             {
-            unsigned n = 8;
+            unsigned n = 1; // one file = one inode lock: more writers only contend
             if (const char* e = getenv("PGSD_WRITERS"))
                 n = (unsigned)atoi(e);
             if (devcfg_set && devcfg.n_writers)
