@@ -160,6 +160,17 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this
+    # process); only reported when it was measured for this particle count
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pack_traffic.json")) as tf:
+            tj = json.load(tf)
+        if tj.get("particles") == N:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     total_bytes = world * args.steps * N * PAYLOAD_BYTES_PER_PARTICLE
     value = total_bytes / dt / 1e9
     achieved = ALGO_BYTES_PER_PARTICLE * N / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
@@ -182,7 +193,7 @@ def main():
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * PAYLOAD_BYTES_PER_PARTICLE,
                    "parallelism": "particle-partition x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "pack_tiles_kernel", "avg_ms": round(pack_ms, 5),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE * N},
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),

@@ -1,0 +1,612 @@
+"""Read and write HOOMD / HOOMD-SPH schema PGSD files, MI355X-native.
+
+Same surface as the reference's ``pgsd.hoomd`` (/root/reference/pgsd/pgsd/hoomd.py):
+``open``, ``HOOMDTrajectory``, ``Frame`` (``ConfigurationData``, ``ParticleData``,
+``ConstraintData``), ``read_log``; the same chunk names, dtypes, shapes and frame-0 /
+default-value fallbacks on read (hoomd.py:724-902).
+
+The reference's writer is disabled (``append`` raises NotImplementedError, hoomd.py:568; its
+intended policy survives only as comments, hoomd.py:569-642).  Here ``append`` is real and
+follows that policy: per-particle arrays are partitioned over the ranks
+(``write_all=True, offset=part_dist``), configuration scalars, ``N``, ``types`` and
+``type_shapes`` are replicated small chunks (``write_all=False``).  Per-particle attributes may
+be **GPU-resident** (torch tensors or :class:`pgsd.fl.DeviceField`), in which case all of them
+are packed by one fused HIP launch and streamed to the file; the per-rank row counts come
+from one allgather over the installed communicator (RCCL over xGMI on GPU ranks).
+"""
+from collections import OrderedDict
+import json
+import logging
+import warnings
+
+import numpy
+
+try:
+    from . import fl
+except ImportError:  # pragma: no cover - the shared library is missing
+    fl = None
+
+from .version import __version__ as _pgsd_version
+
+logger = logging.getLogger('pgsd.hoomd')
+
+
+def _is_device(x):
+    return fl is not None and (isinstance(x, fl.DeviceField) or fl._is_device_tensor(x))
+
+
+def _rows(x):
+    if fl is not None and isinstance(x, fl.DeviceField):
+        return x.N
+    return int(x.shape[0])
+
+
+class ConfigurationData(object):
+    """Store configuration data (hoomd.py:45-108).
+
+    Attributes:
+        step (int): time step of this frame (:chunk:`configuration/step`).
+        dimensions (int): number of dimensions (:chunk:`configuration/dimensions`); defaults to
+            2 when the box has Lz == 0, else 3.
+        box ((6,) float32): [lx, ly, lz, xy, xz, yz] (:chunk:`configuration/box`).
+    """
+
+    _default_value = OrderedDict()
+    _default_value['step'] = numpy.uint64(0)
+    _default_value['dimensions'] = numpy.uint8(3)
+    _default_value['box'] = numpy.array([1, 1, 1, 0, 0, 0], dtype=numpy.float32)
+
+    def __init__(self):
+        self.step = None
+        self.dimensions = None
+        self._box = None
+
+    @property
+    def box(self):
+        return self._box
+
+    @box.setter
+    def box(self, box):
+        self._box = box
+        try:
+            Lz = box[2]
+        except TypeError:
+            return
+        else:
+            if self.dimensions is None:
+                self.dimensions = 2 if Lz == 0 else 3
+
+    def validate(self):
+        """Convert ``box`` to a (6,) float32 array; ignore attributes that are ``None``."""
+        logger.debug('Validating ConfigurationData')
+        if self.box is not None:
+            self.box = numpy.ascontiguousarray(self.box, dtype=numpy.float32)
+            self.box = self.box.reshape([6])
+
+
+# (dtype, columns) of every per-particle chunk; the first block is the PGSD-SPH schema the
+# reference implements (hoomd.py:167-184), the second the upstream HOOMD attributes that the
+# reference documents (hoomd.py:133-158) but leaves out of its reader.
+_PARTICLE_SPEC = OrderedDict([
+    ('typeid', (numpy.uint32, 1)), ('mass', (numpy.float32, 1)), ('body', (numpy.int32, 1)),
+    ('position', (numpy.float32, 3)), ('velocity', (numpy.float32, 3)),
+    ('slength', (numpy.float32, 1)), ('density', (numpy.float32, 1)), ('pressure', (numpy.float32, 1)),
+    ('energy', (numpy.float32, 1)),
+    ('auxiliary1', (numpy.float32, 3)), ('auxiliary2', (numpy.float32, 3)),
+    ('auxiliary3', (numpy.float32, 3)), ('auxiliary4', (numpy.float32, 3)),
+    ('image', (numpy.int32, 3)),
+])
+_PARTICLE_SPEC_EXTRA = OrderedDict([
+    ('charge', (numpy.float32, 1)), ('diameter', (numpy.float32, 1)),
+    ('moment_inertia', (numpy.float32, 3)), ('orientation', (numpy.float32, 4)),
+    ('angmom', (numpy.float32, 4)),
+])
+
+
+class ParticleData(object):
+    """Store particle data chunks (hoomd.py:111-270).
+
+    ``N`` is the number of particles **this rank** holds when writing and the global number
+    when reading.  Array attributes may be numpy arrays / array-likes, or GPU-resident torch
+    tensors / :class:`pgsd.fl.DeviceField` objects (write only).
+    """
+
+    _default_value = OrderedDict()
+    _default_value['N'] = numpy.uint32(0)
+    _default_value['types'] = ['A']
+    _default_value['typeid'] = numpy.uint32(0)
+    _default_value['mass'] = numpy.float32(1.0)
+    _default_value['body'] = numpy.int32(-1)
+    _default_value['position'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['velocity'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['slength'] = numpy.float32(1.0)
+    _default_value['density'] = numpy.float32(0.0)
+    _default_value['pressure'] = numpy.float32(0.0)
+    _default_value['energy'] = numpy.float32(0.0)
+    _default_value['auxiliary1'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['auxiliary2'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['auxiliary3'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['auxiliary4'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _default_value['image'] = numpy.array([0, 0, 0], dtype=numpy.int32)
+    _default_value['type_shapes'] = [{}]
+
+    # upstream HOOMD attributes: written when set, read back when present in the file
+    _extra_default_value = OrderedDict()
+    _extra_default_value['charge'] = numpy.float32(0.0)
+    _extra_default_value['diameter'] = numpy.float32(1.0)
+    _extra_default_value['moment_inertia'] = numpy.array([0, 0, 0], dtype=numpy.float32)
+    _extra_default_value['orientation'] = numpy.array([1, 0, 0, 0], dtype=numpy.float32)
+    _extra_default_value['angmom'] = numpy.array([0, 0, 0, 0], dtype=numpy.float32)
+
+    def __init__(self):
+        self.N = 0
+        self.types = None
+        self.type_shapes = None
+        for name in _PARTICLE_SPEC:
+            setattr(self, name, None)
+        for name in _PARTICLE_SPEC_EXTRA:
+            setattr(self, name, None)
+
+    def validate(self):
+        """Convert host arrays to contiguous arrays of the schema dtype and shape
+        (hoomd.py:206-270); device-resident attributes are only shape-checked."""
+        logger.debug('Validating ParticleData')
+        for spec in (_PARTICLE_SPEC, _PARTICLE_SPEC_EXTRA):
+            for name, (dt, M) in spec.items():
+                value = getattr(self, name)
+                if value is None:
+                    continue
+                if _is_device(value):
+                    if _rows(value) != self.N:
+                        raise ValueError("particles/%s has %d rows, expected N=%d" % (name, _rows(value), self.N))
+                    continue
+                value = numpy.ascontiguousarray(value, dtype=dt)
+                setattr(self, name, value.reshape([self.N]) if M == 1 else value.reshape([self.N, M]))
+        if self.types is not None and (not len(set(self.types)) == len(self.types)):
+            raise ValueError("Type names must be unique.")
+
+
+class ConstraintData(object):
+    """Store constraint data (hoomd.py:365-421): ``N``, ``value`` (N,) float32, ``group`` (N, 2) int32."""
+
+    def __init__(self):
+        self.M = 2
+        self.N = 0
+        self.value = None
+        self.group = None
+        self._default_value = OrderedDict()
+        self._default_value['N'] = numpy.uint32(0)
+        self._default_value['value'] = numpy.float32(0)
+        self._default_value['group'] = numpy.array([0] * self.M, dtype=numpy.int32)
+
+    def validate(self):
+        logger.debug('Validating ConstraintData')
+        if self.value is not None:
+            self.value = numpy.ascontiguousarray(self.value, dtype=numpy.float32)
+            self.value = self.value.reshape([self.N])
+        if self.group is not None:
+            self.group = numpy.ascontiguousarray(self.group, dtype=numpy.int32)
+            self.group = self.group.reshape([self.N, self.M])
+
+
+class Frame(object):
+    """System state at one point in time (hoomd.py:424-467).
+
+    Attributes:
+        configuration (`ConfigurationData`), particles (`ParticleData`),
+        constraints (`ConstraintData`), state (dict), log (dict of array-likes).
+        num_procs (int): number of writer ranks this frame was partitioned for.
+        part_dist: optional integer array with every rank's local particle count; when
+            ``None``, `HOOMDTrajectory.append` obtains it with one allgather.
+    """
+
+    def __init__(self, num_procs=0):
+        self.configuration = ConfigurationData()
+        self.particles = ParticleData()
+        self.constraints = ConstraintData()
+        self.state = {}
+        self.log = {}
+        self.num_procs = num_procs
+        self.part_dist = None
+
+    def validate(self):
+        """Validate all contained frame data."""
+        self.configuration.validate()
+        self.particles.validate()
+        self.constraints.validate()
+
+
+class _HOOMDTrajectoryIterable(object):
+    """Iterable over a HOOMDTrajectory object."""
+
+    def __init__(self, trajectory, indices):
+        self._trajectory = trajectory
+        self._indices = indices
+        self._indices_iterator = iter(indices)
+
+    def __next__(self):
+        return self._trajectory[next(self._indices_iterator)]
+
+    next = __next__
+
+    def __iter__(self):
+        return type(self)(self._trajectory, self._indices)
+
+    def __len__(self):
+        return len(self._indices)
+
+
+class _HOOMDTrajectoryView(object):
+    """A view of a HOOMDTrajectory object (slicing / iteration over a subset)."""
+
+    def __init__(self, trajectory, indices):
+        self._trajectory = trajectory
+        self._indices = indices
+
+    def __iter__(self):
+        return _HOOMDTrajectoryIterable(self._trajectory, self._indices)
+
+    def __len__(self):
+        return len(self._indices)
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return type(self)(self._trajectory, self._indices[key])
+        return self._trajectory[self._indices[key]]
+
+
+def _encode_strings(strings):
+    """list[str] -> (n, wid) int8 array, NUL padded (hoomd.py:628-630)."""
+    wid = max(len(w.encode('utf-8')) for w in strings) + 1
+    b = numpy.array([w.encode('utf-8') for w in strings], dtype=numpy.dtype((bytes, wid)))
+    return b.view(dtype=numpy.int8).reshape(len(b), wid)
+
+
+class HOOMDTrajectory(object):
+    """Read and write hoomd pgsd files (hoomd.py:515-940).
+
+    Args:
+        file (`pgsd.fl.PGSDFile` or `pgsd.pypgsd.PGSDFile`): file to access.
+    """
+
+    def __init__(self, file):
+        if file.mode == 'ab':
+            raise ValueError('Append mode not yet supported')
+        self._file = file
+        self._initial_frame = None
+        logger.info('opening HOOMDTrajectory: ' + str(self.file))
+        if self.file.schema != 'hoomd':
+            raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
+        version = self.file.schema_version
+        if not (version < (2, 0) and version >= (1, 0)):
+            raise RuntimeError('Incompatible hoomd schema version ' + str(version) + ' in: ' + str(self.file))
+        logger.info('found ' + str(len(self)) + ' frames')
+
+    @property
+    def file(self):
+        """The file handle."""
+        return self._file
+
+    def __len__(self):
+        """The number of frames in the trajectory."""
+        return self.file.nframes
+
+    # ------------------------------------------------------------------ writing
+    def _comm(self):
+        from ._lib import lib
+        return lib.pgsd_comm_rank(), lib.pgsd_comm_size()
+
+    def append(self, frame):
+        """Append a frame (collective over the ranks of the installed communicator).
+
+        Fields that are ``None`` are not written.  Host fields that equal the initial frame or
+        the default value are elided exactly as upstream GSD does (hoomd.py:654-694); ranks
+        agree on each decision (a chunk is written if any rank needs it).  GPU-resident fields
+        are always written.
+        """
+        logger.debug('Appending frame to hoomd trajectory: ' + str(self.file))
+        frame.validate()
+        rank, size = self._comm()
+
+        # per-rank particle counts -> file offsets (the allgather of benchmark-write.cc:41)
+        if frame.part_dist is not None:
+            part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
+            if part_dist.shape[0] != size:
+                raise ValueError("part_dist must have one entry per rank")
+        else:
+            from . import dist as _dist
+            part_dist, _, _ = _dist.partition_rows(int(frame.particles.N))
+        n_global = int(part_dist.sum())
+
+        # the initial frame is the reference for elision
+        if self._initial_frame is None and len(self) > 0:
+            self._read_frame(0)
+
+        # 1. decide which chunks to write (local), then agree over the ranks
+        plan = []
+        for path in ('configuration', 'particles', 'constraints'):
+            container = getattr(frame, path)
+            names = list(container._default_value)
+            if path == 'particles':
+                names += list(container._extra_default_value)
+            for name in names:
+                plan.append((path, name, self._should_write(path, name, frame, n_global)))
+        if size > 1:
+            from ._lib import lib
+            import ctypes
+            mine = numpy.array([1 if w else 0 for _, _, w in plan], dtype=numpy.uint8)
+            allb = numpy.zeros(size * len(mine), dtype=numpy.uint8)
+            rc = lib.pgsd_comm_allgather(mine.ctypes.data_as(ctypes.c_void_p), allb.ctypes.data_as(ctypes.c_void_p),
+                                         len(mine))
+            if rc != 0:
+                raise RuntimeError("communicator allgather failed")
+            agreed = allb.reshape(size, len(mine)).max(axis=0)
+            plan = [(p, n, bool(a)) for (p, n, _), a in zip(plan, agreed)]
+
+        # 2. write, in the reference's chunk order; device fields go out in one fused launch
+        device_fields = []
+        for path, name, write in plan:
+            if not write:
+                continue
+            container = getattr(frame, path)
+            data = getattr(container, name)
+            chunk = path + '/' + name
+            logger.debug('writing data chunk: ' + chunk)
+            if path == 'particles' and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
+                dt, M = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
+                if data is None:
+                    # another rank needs the chunk: contribute this rank's rows of the default
+                    default = container._default_value.get(name, container._extra_default_value.get(name))
+                    data = numpy.empty([frame.particles.N] + ([M] if M > 1 else []), dtype=dt)
+                    data[...] = default
+                if _is_device(data):
+                    f = data if isinstance(data, fl.DeviceField) else fl.DeviceField.from_tensor(data, out_dtype=dt)
+                    device_fields.append((chunk, f))
+                else:
+                    self._flush_device_fields(device_fields, part_dist, rank)
+                    self.file.write_chunk(chunk, data, part_dist, rank, True)
+                continue
+            self._flush_device_fields(device_fields, part_dist, rank)
+            # replicated small chunks (hoomd.py:604-630)
+            if name == 'N':
+                count = n_global if path == 'particles' else int(container.N)
+                data = numpy.array([count], dtype=numpy.uint32)
+            elif name == 'step':
+                data = numpy.array([data], dtype=numpy.uint64)
+            elif name == 'dimensions':
+                data = numpy.array([data], dtype=numpy.uint8)
+            elif name in ('types', 'type_shapes'):
+                if name == 'type_shapes':
+                    data = [json.dumps(shape_dict) for shape_dict in data]
+                data = _encode_strings(data)
+            self.file.write_chunk(chunk, data, None, rank, False)
+        self._flush_device_fields(device_fields, part_dist, rank)
+
+        # logged quantities are replicated
+        for log, data in frame.log.items():
+            self.file.write_chunk('log/' + log, data, None, rank, False)
+
+        self.file.end_frame()
+
+    def _flush_device_fields(self, device_fields, part_dist, rank):
+        if device_fields:
+            self.file.write_chunks(list(device_fields), offset=part_dist, rank=rank)
+            del device_fields[:]
+
+    def _should_write(self, path, name, frame, n_global):
+        """False if the value is None, matches the initial frame, or matches the default and
+        frame 0 has no such chunk (hoomd.py:654-694)."""
+        container = getattr(frame, path)
+        data = getattr(container, name, None)
+        if name == 'N' and path == 'particles':
+            data = n_global
+        if data is None:
+            return False
+        if _is_device(data):
+            return True
+        if self._initial_frame is not None:
+            initial_container = getattr(self._initial_frame, path)
+            initial_data = getattr(initial_container, name, None)
+            if initial_data is not None and numpy.array_equal(initial_data, data):
+                logger.debug('skipping data chunk, matches frame 0: ' + path + '/' + name)
+                return False
+        default = container._default_value.get(name)
+        if default is None and path == 'particles':
+            default = container._extra_default_value.get(name)
+        if name in ('types', 'type_shapes'):
+            matches_default_value = data == default
+        else:
+            matches_default_value = numpy.array_equiv(data, default)
+        if matches_default_value and not self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
+            logger.debug('skipping data chunk, default value: ' + path + '/' + name)
+            return False
+        return True
+
+    def extend(self, iterable):
+        """Append each item of the iterable to the file."""
+        for item in iterable:
+            self.append(item)
+
+    def close(self):
+        """Close the file."""
+        self.file.close()
+        del self._initial_frame
+
+    def flush(self):
+        """Flush all buffered frames to the file."""
+        self._file.flush()
+
+    # ------------------------------------------------------------------ reading
+    def read_frame(self, idx):
+        """Read the frame at the given index (deprecated alias of ``trajectory[idx]``)."""
+        warnings.warn("Deprecated, trajectory[idx]", DeprecationWarning)
+        return self._read_frame(idx)
+
+    def _read_scalar(self, idx, chunk, container, attr, fallback_path):
+        if self.file.chunk_exists(frame=idx, name=chunk, write_all=False):
+            arr = self.file.read_chunk(frame=idx, name=chunk, offset=numpy.uint32(0), r_all=False)
+            setattr(container, attr, arr[0])
+        elif self._initial_frame is not None:
+            setattr(container, attr, getattr(getattr(self._initial_frame, fallback_path), attr))
+        else:
+            setattr(container, attr, container._default_value[attr])
+
+    def _read_frame(self, idx):
+        """Read one frame; chunks missing in the frame come from frame 0 (when N matches) or
+        from the default values, returned read-only (hoomd.py:724-902)."""
+        if idx >= len(self):
+            raise IndexError
+        logger.debug('reading frame ' + str(idx) + ' from: ' + str(self.file))
+        if self._initial_frame is None and idx != 0:
+            self._read_frame(0)
+
+        snap = Frame()
+        self._read_scalar(idx, 'configuration/step', snap.configuration, 'step', 'configuration')
+        self._read_scalar(idx, 'configuration/dimensions', snap.configuration, 'dimensions', 'configuration')
+        if self.file.chunk_exists(frame=idx, name='configuration/box', write_all=False):
+            snap.configuration.box = self.file.read_chunk(frame=idx, name='configuration/box',
+                                                          offset=numpy.uint32(0), r_all=False)
+        elif self._initial_frame is not None:
+            snap.configuration.box = self._initial_frame.configuration.box
+        else:
+            snap.configuration.box = snap.configuration._default_value['box']
+
+        for path in ('particles', 'constraints'):
+            container = getattr(snap, path)
+            initial = getattr(self._initial_frame, path) if self._initial_frame is not None else None
+
+            container.N = 0
+            if self.file.chunk_exists(frame=idx, name=path + '/N', write_all=False):
+                container.N = self.file.read_chunk(frame=idx, name=path + '/N', offset=numpy.uint32(0),
+                                                   r_all=False)[0]
+            elif initial is not None:
+                container.N = initial.N
+
+            if 'types' in container._default_value:
+                if self.file.chunk_exists(frame=idx, name=path + '/types', write_all=False):
+                    tmp = self.file.read_chunk(frame=idx, name=path + '/types', offset=numpy.uint32(0), r_all=False)
+                    tmp = tmp.view(dtype=numpy.dtype((bytes, tmp.shape[1]))).reshape([tmp.shape[0]])
+                    container.types = list(a.decode('UTF-8') for a in tmp)
+                elif initial is not None:
+                    container.types = initial.types
+                else:
+                    container.types = container._default_value['types']
+
+            if 'type_shapes' in container._default_value and path == 'particles':
+                if self.file.chunk_exists(frame=idx, name=path + '/type_shapes', write_all=False):
+                    tmp = self.file.read_chunk(frame=idx, name=path + '/type_shapes', offset=numpy.uint32(0),
+                                               r_all=False)
+                    tmp = tmp.view(dtype=numpy.dtype((bytes, tmp.shape[1]))).reshape([tmp.shape[0]])
+                    container.type_shapes = list(json.loads(s.decode('UTF-8')) for s in tmp)
+                elif initial is not None:
+                    container.type_shapes = initial.type_shapes
+                else:
+                    container.type_shapes = container._default_value['type_shapes']
+
+            defaults = list(container._default_value.items())
+            optional = list(container._extra_default_value.items()) if path == 'particles' else []
+            optional_names = set(n for n, _ in optional)
+            for name, default in defaults + optional:
+                if name in ('N', 'types', 'type_shapes'):
+                    continue
+                chunk = path + '/' + name
+                is_optional = name in optional_names
+                if self.file.chunk_exists(frame=idx, name=chunk, write_all=False):
+                    container.__dict__[name] = self.file.read_chunk(frame=idx, name=chunk, offset=numpy.uint32(0),
+                                                                    r_all=False)
+                    continue
+                if is_optional and (initial is None or initial.__dict__.get(name) is None):
+                    continue  # upstream-only attribute that this file never stored
+                if initial is not None and initial.N == container.N and initial.__dict__.get(name) is not None:
+                    container.__dict__[name] = initial.__dict__[name]
+                else:
+                    tmp = numpy.array([default])
+                    s = list(tmp.shape)
+                    s[0] = container.N
+                    container.__dict__[name] = numpy.empty(shape=s, dtype=tmp.dtype)
+                    container.__dict__[name][:] = tmp
+                container.__dict__[name].flags.writeable = False
+
+        for log in self.file.find_matching_chunk_names('log/', False):
+            if self.file.chunk_exists(frame=idx, name=log, write_all=False):
+                snap.log[log[4:]] = self.file.read_chunk(frame=idx, name=log, offset=numpy.uint32(0), r_all=False)
+            elif self._initial_frame is not None and log[4:] in self._initial_frame.log:
+                snap.log[log[4:]] = self._initial_frame.log[log[4:]]
+
+        if self._initial_frame is None and idx == 0:
+            self._initial_frame = snap
+        return snap
+
+    def __getitem__(self, key):
+        """Index trajectory frames (int, negative int or slice, like a list)."""
+        if isinstance(key, slice):
+            return _HOOMDTrajectoryView(self, range(*key.indices(len(self))))
+        elif isinstance(key, (int, numpy.integer)):
+            key = int(key)
+            if key < 0:
+                key += len(self)
+            if key >= len(self) or key < 0:
+                raise IndexError()
+            return self._read_frame(key)
+        else:
+            raise TypeError
+
+    def __iter__(self):
+        return _HOOMDTrajectoryIterable(self, range(len(self)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self.file.close()
+
+
+def open(name, mode='r'):
+    """Open a hoomd schema PGSD file (hoomd.py:943-989).
+
+    Valid modes: ``'r'``, ``'r+'``, ``'w'``, ``'x'``, ``'a'``.  Returns a `HOOMDTrajectory`.
+    """
+    if fl is None:
+        raise RuntimeError("file layer module is not available")
+    pgsdfileobj = fl.open(name=str(name), mode=mode, application='pgsd.hoomd ' + _pgsd_version,
+                          schema='hoomd', schema_version=[1, 4])
+    return HOOMDTrajectory(pgsdfileobj)
+
+
+def read_log(name, scalar_only=False):
+    """Read ``configuration/step`` and every ``log/*`` quantity into a dict of time-series arrays
+    (hoomd.py:992-1075).  Quantities must keep their shape over the frames."""
+    if fl is None:
+        raise RuntimeError("file layer module is not available")
+    with fl.open(name=str(name), mode='r', application='pgsd.hoomd ' + _pgsd_version, schema='hoomd',
+                 schema_version=[1, 4]) as f:
+        names = f.find_matching_chunk_names('log/')
+        names.insert(0, 'configuration/step')
+        if len(names) == 1:
+            warnings.warn('No logged data in file: ' + str(name), RuntimeWarning)
+        out = dict()
+        nframes = f.nframes
+        for log in names:
+            exists0 = f.chunk_exists(frame=0, name=log, write_all=False)
+            is_step = log == 'configuration/step'
+            if exists0 or is_step:
+                if is_step and not exists0:
+                    tmp = numpy.array([0], dtype=numpy.uint64)
+                else:
+                    tmp = f.read_chunk(frame=0, name=log)
+                if scalar_only and not tmp.shape[0] == 1:
+                    continue
+                if tmp.shape[0] == 1:
+                    out[log] = numpy.full(fill_value=tmp[0], shape=(nframes,))
+                else:
+                    out[log] = numpy.tile(tmp, (nframes,) + tuple(1 for _ in tmp.shape))
+        for idx in range(1, nframes):
+            for log in out.keys():
+                if not f.chunk_exists(frame=idx, name=log, write_all=False):
+                    continue
+                data = f.read_chunk(frame=idx, name=log)
+                if len(out[log][idx].shape) == 0:
+                    out[log][idx] = data[0]
+                else:
+                    out[log][idx] = data
+    return out

@@ -24,5 +24,7 @@ for scn in tests/golden/scenarios/*.scn; do
     mv /tmp/golden_$$.gsd "$OUT/$name.p$p.gsd"
   done
 done
+# the reference's own GSD v1.0 read fixture (data file of its test suite, test_fl.py:613-651)
+cp /root/reference/pgsd/pgsd/test/test_gsd_v1.gsd "$OUT/reference_test_gsd_v1.gsd"
 ( cd "$OUT" && sha256sum *.gsd *.log > SHA256SUMS )
 du -sh "$OUT"

@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/pgsd.h declares."""
+import ctypes
+import os
+import re
+
+import product
+
+
+def declared_symbols():
+    hdr = open(os.path.join(product.ROOT, "include", "pgsd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(pgsd_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ctypes.CDLL(product.build())
+    names = declared_symbols()
+    # the sixteen entry points of the reference ABI (pgsd.h:362-735) must be among them
+    for ref in ("pgsd_make_version", "pgsd_create_and_open", "pgsd_open", "pgsd_close", "pgsd_end_frame",
+                "pgsd_flush", "pgsd_write_chunk", "pgsd_find_chunk", "pgsd_read_chunk", "pgsd_get_nframes",
+                "pgsd_get_nnames", "pgsd_sizeof_type", "pgsd_find_matching_chunk_name",
+                "pgsd_get_maximum_write_buffer_size", "pgsd_set_maximum_write_buffer_size",
+                "pgsd_get_index_entries_to_buffer", "pgsd_set_index_entries_to_buffer",
+                "pgsd_bcast_index_entry"):
+        assert ref in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert len(names) >= 40
+
+
+def test_struct_layouts_match_the_format():
+    from pgsd import _lib
+    assert ctypes.sizeof(_lib.Header) == 256
+    assert ctypes.sizeof(_lib.IndexEntry) == 32
+    assert _lib.lib.pgsd_sizeof_type(9) == 4 and _lib.lib.pgsd_sizeof_type(10) == 8
+    assert _lib.lib.pgsd_sizeof_type(0) == 0 and _lib.lib.pgsd_sizeof_type(11) == 0
+    assert _lib.lib.pgsd_make_version(1, 4) == (1 << 16 | 4)
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    """No CPU stand-in: on a box without a GPU the device calls return PGSD_ERROR_NO_DEVICE."""
+    from pgsd import _lib
+    if _lib.lib.pgsd_device_available():
+        return
+    job = (_lib.PackJob * 1)()
+    assert _lib.lib.pgsd_pack_fields(1, job, 16, None) == _lib.ERROR_NO_DEVICE
+    assert "no HIP device" in _lib.last_error()
+    ws = ctypes.c_uint64(0)
+    assert _lib.lib.pgsd_select_rows(None, 0, None, ctypes.byref(ws), ctypes.byref(ws), None) == _lib.ERROR_NO_DEVICE
+
+
+def test_device_write_without_gpu_raises(tmp_gsd):
+    import numpy as np
+    import pytest
+    import pgsd.fl as fl
+    from pgsd import _lib
+    if _lib.lib.pgsd_device_available():
+        return
+    with fl.open(tmp_gsd, 'w', application='a', schema='s', schema_version=[1, 0]) as f:
+        field = fl.DeviceField(ptr=0x1000, dtype=np.float32, N=8, M=3, stride=4)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            f.write_chunk('particles/position', field)
