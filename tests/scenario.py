@@ -81,11 +81,12 @@ def scenario_path(name):
 
 def golden_cases():
     """[(scenario, P)] for every committed golden file."""
+    import re
     out = []
     for fn in sorted(os.listdir(GOLDEN)):
-        if fn.endswith(".gsd"):
-            name, p, _ = fn.split(".")
-            out.append((name, int(p[1:])))
+        m = re.match(r"^([a-z_]+)\.p(\d+)\.gsd$", fn)
+        if m and os.path.exists(scenario_path(m.group(1))):
+            out.append((m.group(1), int(m.group(2))))
     return out
 
 
