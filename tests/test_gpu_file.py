@@ -189,3 +189,72 @@ def test_multi_rank_device_write_matches_oracle(counts, tmp_path):
     _oracle_frames(ref, P, frames)
     with open(mine, 'rb') as a, open(ref, 'rb') as b:
         assert a.read() == b.read()
+
+
+def test_hoomd_append_with_device_fields(tmp_path):
+    """pgsd.hoomd.HOOMDTrajectory.append with GPU-resident attributes (one fused launch) equals
+    the same trajectory written from host copies."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    N = 12345
+    rng = np.random.default_rng(4)
+    gpu_path, cpu_path = str(tmp_path / "gpu.gsd"), str(tmp_path / "cpu.gsd")
+    tg, tc = hoomd.open(gpu_path, 'w'), hoomd.open(cpu_path, 'w')
+    for i in range(3):
+        pos4 = G.rand_array(rng, (N, 4), np.float64)
+        vel4 = G.rand_array(rng, (N, 4), np.float32)
+        tid = rng.integers(0, 3, size=N, dtype=np.uint32)
+        vel4[:, 3] = rng.random(N, dtype=np.float32) + 1.0          # mass in w
+        dens = G.rand_array(rng, (N,), np.float32)
+        dpos, dvel, dtid, ddens = dev(pos4), dev(vel4), dev(tid.view(np.int32)), dev(dens)
+        for t, on_gpu in ((tg, True), (tc, False)):
+            f = hoomd.Frame()
+            f.configuration.step = 7 * i + 1
+            f.configuration.box = [20, 20, 20, 0, 0, 0]
+            f.particles.N = N
+            f.particles.types = ['a', 'b', 'c']
+            if on_gpu:
+                f.particles.position = fl.DeviceField.from_tensor(dpos, columns=(0, 3), out_dtype=np.float32)
+                f.particles.velocity = fl.DeviceField.from_tensor(dvel, columns=(0, 3))
+                f.particles.mass = fl.DeviceField.from_tensor(dvel, columns=(3, 4))
+                f.particles.typeid = fl.DeviceField.from_tensor(dtid, out_dtype=np.uint32)
+                f.particles.density = ddens
+            else:
+                f.particles.position = pos4[:, :3].astype(np.float32)
+                f.particles.velocity = vel4[:, :3]
+                f.particles.mass = vel4[:, 3]
+                f.particles.typeid = tid
+                f.particles.density = dens
+            t.append(f)
+    tg.close()
+    tc.close()
+    # device fields are never elided, host fields equal to frame 0 are: compare contents
+    with hoomd.open(gpu_path, 'r') as a, hoomd.open(cpu_path, 'r') as b:
+        assert len(a) == len(b) == 3
+        for i in range(3):
+            sa, sb = a[i], b[i]
+            assert sa.configuration.step == sb.configuration.step and sa.particles.types == sb.particles.types
+            for name in ('position', 'velocity', 'mass', 'typeid', 'density'):
+                ga, gb = getattr(sa.particles, name), getattr(sb.particles, name)
+                assert ga.dtype == gb.dtype and ga.tobytes() == gb.tobytes(), name
+
+
+def test_rccl_communicator_single_rank():
+    """The native RCCL back end (dlopen, ncclCommInitRank, ncclAllGather on the private stream);
+    more than one rank needs more than one GPU, so the multi-rank run is bench.py --gpus N."""
+    import ctypes
+    from pgsd import _lib
+    import pgsd.dist as pdist
+    uid = (ctypes.c_uint8 * 128)()
+    assert _lib.lib.pgsd_comm_rccl_unique_id(uid) == 0, _lib.last_error()
+    assert _lib.lib.pgsd_comm_init_rccl(uid, 0, 1, 0) == 0, _lib.last_error()
+    try:
+        counts, row0, n_global = pdist.partition_rows(4242)
+        assert list(counts) == [4242] and row0 == 0 and n_global == 4242
+        send = (ctypes.c_uint8 * 300)(*range(44, 344 - 44) if False else [i % 251 for i in range(300)])
+        recv = (ctypes.c_uint8 * 300)()
+        assert _lib.lib.pgsd_comm_allgather(send, recv, 300) == 0
+        assert bytes(recv) == bytes(send)
+        assert _lib.lib.pgsd_comm_barrier() == 0
+    finally:
+        pdist.finalize()
