@@ -100,7 +100,15 @@ def main():
 
     import pgsd.fl as fl
     import pgsd.dist as pdist
-    comm_backend = pdist.init_from_torch(device=local_rank) if world > 1 else "self"
+    comm_backend = "self"
+    if world > 1:
+        try:
+            # native RCCL communicator (ncclAllGather over xGMI issued from the C++ library)
+            comm_backend = pdist.init_from_torch(device=local_rank)
+        except RuntimeError as e:  # keep the run alive on a host-callback communicator
+            print("bench.py: RCCL communicator unavailable (%s); using torch.distributed callbacks" % e,
+                  file=sys.stderr)
+            comm_backend = pdist.init_from_torch(device=local_rank, prefer_rccl=False)
 
     N = args.particles
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -196,6 +204,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "pack_tiles_kernel", "avg_ms": round(pack_ms, 5),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE * N},
+        "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
+                           "note": "sum over ranks of the pack kernel rate (independent kernels, one per GPU)"},
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }

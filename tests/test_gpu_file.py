@@ -258,3 +258,48 @@ def test_rccl_communicator_single_rank():
         assert _lib.lib.pgsd_comm_barrier() == 0
     finally:
         pdist.finalize()
+
+
+def test_full_size_frame_matches_oracle_file(tmp_path):
+    """BASELINE config 3 at its real size: 10 M particles, position+velocity+typeid from float4 /
+    int32 arrays in HBM, two frames (560 MB of chunks) -- the file must be byte-identical to the
+    one the CPU oracle writes from host copies of the same values."""
+    import hashlib
+    import pgsd.fl as fl
+    N = 10_000_000
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    mine = os.path.join(d, "pgsd_full_mine_%d.gsd" % os.getpid())
+    ref = os.path.join(d, "pgsd_full_ref_%d.gsd" % os.getpid())
+    try:
+        g = torch.Generator(device="cuda").manual_seed(1234)
+        f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+        frames = []
+        for frame in range(2):
+            pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
+            vel = torch.randn((N, 4), generator=g, device="cuda")
+            tid = torch.randperm(N, generator=g, device="cuda").to(torch.int32)
+            f.write_chunk('configuration/step', np.array([frame], dtype=np.uint64), write_all=False)
+            f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3))),
+                            ('particles/velocity', fl.DeviceField.from_tensor(vel, columns=(0, 3))),
+                            ('particles/typeid', fl.DeviceField.from_tensor(tid, out_dtype=np.uint32))],
+                           offset=np.array([N]))
+            f.end_frame()
+            frames.append([('configuration/step', 4, 1, False, [np.array([[frame]], dtype=np.uint64)]),
+                           ('particles/position', 9, 3, True, [np.ascontiguousarray(pos.cpu().numpy()[:, :3])]),
+                           ('particles/velocity', 9, 3, True, [np.ascontiguousarray(vel.cpu().numpy()[:, :3])]),
+                           ('particles/typeid', 3, 1, True, [tid.cpu().numpy().view(np.uint32).reshape(-1, 1)])])
+        f.close()
+        _oracle_frames(ref, 1, frames)
+        assert os.path.getsize(mine) == os.path.getsize(ref)
+
+        def digest(p):
+            h = hashlib.sha256()
+            with open(p, 'rb') as fh:
+                for block in iter(lambda: fh.read(1 << 24), b''):
+                    h.update(block)
+            return h.hexdigest()
+        assert digest(mine) == digest(ref)
+    finally:
+        for p in (mine, ref):
+            if os.path.exists(p):
+                os.unlink(p)
