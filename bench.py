@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--slab-mib", type=int, default=0)
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,10 +95,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_shared_gpu:
+            dist.init_process_group(backend="gloo")
+            red_dev = "cpu"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import pgsd.fl as fl
     import pgsd.dist as pdist
@@ -149,10 +158,10 @@ def main():
     f.close()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        pk = torch.tensor([stats["pack_ms"] / max(stats["pack_launches"], 1)], dtype=torch.float64, device="cuda")
+        pk = torch.tensor([stats["pack_ms"] / max(stats["pack_launches"], 1)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(pk, op=dist.ReduceOp.MAX)
         pack_ms = float(pk.item())
     else:
