@@ -338,6 +338,13 @@ extern "C"
         };
     int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg);
 
+    /* Stream ordering: the pack kernels run on a private stream.  Every device write first
+       records an event on the caller's *source stream* -- the stream on which the kernels that
+       produce the particle arrays were enqueued (hipStream_t as void*; NULL = the null stream,
+       which is also PyTorch's default stream) -- and makes the pack stream wait for it, so
+       arrays still being written by earlier asynchronous work are packed only when complete. */
+    int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* stream);
+
     struct pgsd_device_stats
         {
         uint64_t pack_launches;     /* kernels launched since open / last reset */

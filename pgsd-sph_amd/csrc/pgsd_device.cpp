@@ -133,6 +133,16 @@ class DevicePipeline
             bytes_out += bytes;
             }
 
+        // order the pack after whatever the caller enqueued on its source stream
+        hipEvent_t ready;
+        HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_misc_events.push_back(ready);
+            }
+        HIP_TRY(hipEventRecord(ready, m_source_stream));
+        HIP_TRY(hipStreamWaitEvent(m_pack_stream, ready, 0));
+
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (m_cfg.profile)
             {
@@ -191,6 +201,11 @@ class DevicePipeline
                 }
             }
         return PGSD_SUCCESS;
+        }
+
+    void set_source_stream(void* stream)
+        {
+        m_source_stream = (hipStream_t)stream;
         }
 
     int wait_packed()
@@ -469,6 +484,7 @@ class DevicePipeline
     int m_fd;
     bool m_ok = false;
     hipStream_t m_pack_stream = nullptr, m_copy_stream = nullptr;
+    hipStream_t m_source_stream = nullptr; // null stream unless the caller names another
     std::vector<Slab> m_slabs;
     std::deque<uint32_t> m_free_slabs;
     std::vector<Arena> m_arenas;
@@ -526,6 +542,11 @@ int device_pipeline_drain(DevicePipeline* p, std::string* err)
     if (rc != PGSD_SUCCESS && err)
         *err = p->error();
     return rc;
+    }
+
+void device_pipeline_set_source_stream(DevicePipeline* p, void* stream)
+    {
+    p->set_source_stream(stream);
     }
 
 void device_pipeline_stats(DevicePipeline* p, pgsd_device_stats* out, int reset)

@@ -1332,6 +1332,18 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
     return rc;
     }
 
+extern "C" int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* stream)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = ensure_device(s);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    device_pipeline_set_source_stream(s->dev, stream);
+    return PGSD_SUCCESS;
+    }
+
 extern "C" int pgsd_device_wait_packed(struct pgsd_handle* handle)
     {
     Impl* s = impl_of(handle);

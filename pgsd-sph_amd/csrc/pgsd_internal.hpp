@@ -53,6 +53,7 @@ void device_pipeline_destroy(DevicePipeline*);
 // one fused pack launch for `chunks` (all share N), then async copy + write of each
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
 int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
+void device_pipeline_set_source_stream(DevicePipeline*, void* stream);
 int device_pipeline_drain(DevicePipeline*, std::string* err);
 void device_pipeline_stats(DevicePipeline*, pgsd_device_stats* out, int reset);
 bool device_pipeline_idle(DevicePipeline*);

@@ -204,6 +204,7 @@ class PGSDFile(object):
         self.__name = name
         self.__handle = _lib.Handle()
         self.__keepalive = []
+        self.__explicit_stream = False
 
         if overwrite:
             if application is None:
@@ -311,7 +312,22 @@ class PGSDFile(object):
                                       stride, N_global * M, bool(write_all), 0, ptr)
         _raise_on_error(retval, self.__name)
 
+    def _sync_source_stream(self):
+        """Tell the pipeline which stream produced the arrays: PyTorch's current stream."""
+        if _lib._torch is not None and _lib._torch.cuda.is_available():
+            stream = _lib._torch.cuda.current_stream().cuda_stream
+            _raise_on_error(lib.pgsd_device_set_source_stream(self._h(), ctypes.c_void_p(stream)), self.__name)
+
+    def set_source_stream(self, stream):
+        """Name the HIP stream (integer handle) on which the particle arrays are produced;
+        device writes are ordered after the work already enqueued there."""
+        self._check_open()
+        _raise_on_error(lib.pgsd_device_set_source_stream(self._h(), ctypes.c_void_p(stream)), self.__name)
+        self.__explicit_stream = True
+
     def _write_chunk_device(self, name, data, offset, rank, write_all):
+        if not self.__explicit_stream:
+            self._sync_source_stream()
         f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
         N, M = f.N, f.M
         N_global = N
@@ -337,6 +353,8 @@ class PGSDFile(object):
             offset, rank: as in :meth:`write_chunk` (``write_all`` is implied).
         """
         self._check_open()
+        if not self.__explicit_stream:
+            self._sync_source_stream()
         specs = []
         for name, data in fields:
             f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
