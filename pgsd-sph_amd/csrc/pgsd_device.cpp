@@ -41,7 +41,7 @@ namespace pgsd_amd
 class DevicePipeline
     {
     public:
-    DevicePipeline(const pgsd_device_config& cfg, int fd) : m_cfg(cfg), m_fd(fd) { }
+    DevicePipeline(const pgsd_device_config& cfg, int fd, bool shared_file) : m_cfg(cfg), m_fd(fd), m_shared(shared_file) { }
 
     int init()
         {
@@ -452,7 +452,7 @@ class DevicePipeline
         else
             {
             auto t0 = std::chrono::steady_clock::now();
-            int w = pwrite_full(m_fd, s.host, n, foff);
+            int w = pwrite_locked(m_fd, s.host, n, foff, m_shared);
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (w != 0)
                 fail(std::string("pwrite: ") + strerror(-w), true);
@@ -482,6 +482,7 @@ class DevicePipeline
 
     pgsd_device_config m_cfg;
     int m_fd;
+    bool m_shared; // other processes write the same file
     bool m_ok = false;
     hipStream_t m_pack_stream = nullptr, m_copy_stream = nullptr;
     hipStream_t m_source_stream = nullptr; // null stream unless the caller names another
@@ -502,9 +503,9 @@ class DevicePipeline
     pgsd_device_stats m_stats = {};
     };
 
-DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, std::string* err)
+DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, bool shared_file, std::string* err)
     {
-    DevicePipeline* p = new DevicePipeline(cfg, fd);
+    DevicePipeline* p = new DevicePipeline(cfg, fd, shared_file);
     if (p->init() != PGSD_SUCCESS)
         {
         if (err)

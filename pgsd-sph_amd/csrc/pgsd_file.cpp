@@ -814,7 +814,7 @@ static int ensure_device(Impl* s)
         cfg.device = -1;
         }
     std::string err;
-    s->dev = device_pipeline_create(cfg, s->fd, &err);
+    s->dev = device_pipeline_create(cfg, s->fd, s->P > 1, &err);
     if (!s->dev)
         {
         set_last_error(err);
@@ -987,7 +987,7 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
         else if (pl.write && pl.size > 0)
             {
             // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
-            int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset);
+            int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
             if (e != 0)
                 {
                 errno = -e;

@@ -34,7 +34,10 @@ void writer_pool_submit(WriterPool*, std::function<void()> fn);
 unsigned writer_pool_size(WriterPool*);
 // Write [buf, buf+bytes) at `offset` of fd, split over the pool; blocks until done.
 // Returns 0 or -errno.
-int writer_pool_pwrite_sync(WriterPool*, int fd, const void* buf, size_t bytes, long long offset);
+int writer_pool_pwrite_sync(WriterPool*, int fd, const void* buf, size_t bytes, long long offset,
+                            bool shared_file = false);
+// pwrite_full under an advisory flock when several processes write the same file
+int pwrite_locked(int fd, const void* buf, size_t bytes, long long offset, bool shared_file);
 // plain full-length pwrite / pread loops (0 / -errno; pread leaves a short tail untouched)
 int pwrite_full(int fd, const void* buf, size_t bytes, long long offset);
 void pread_some(int fd, void* buf, size_t bytes, long long offset);
@@ -48,7 +51,7 @@ struct DeviceChunk
     long long file_offset;  // where this rank's rows start in the file; <0: copy into host_dst
     void* host_dst;         // for small buffered chunks: synchronous copy target
     };
-DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, std::string* err);
+DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, bool shared_file, std::string* err);
 void device_pipeline_destroy(DevicePipeline*);
 // one fused pack launch for `chunks` (all share N), then async copy + write of each
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
