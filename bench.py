@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--slab-mib", type=int, default=0)
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
+    ap.add_argument("--separate-id", action="store_true", help="typeid from its own uint32 array instead of pos.w")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -120,13 +121,23 @@ def main():
             comm_backend = pdist.init_from_torch(device=local_rank, prefer_rccl=False)
 
     N = args.particles
+    # HOOMD's own device layout (ParticleData: Scalar4 pos = x, y, z, __int_as_scalar(type);
+    # Scalar4 vel = vx, vy, vz, mass).  --separate-id keeps the id in its own uint32 array as
+    # SURVEY.md 8(d) sketches; both layouts have 56 algorithmic bytes per particle.
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
     vel = torch.randn((N, 4), generator=g, device="cuda")
     tid = torch.randperm(N, generator=g, device="cuda").to(torch.int32)
+    if args.separate_id:
+        id_field = fl.DeviceField.from_tensor(tid, out_dtype=np.uint32)
+        layout = "float4 pos, float4 vel, separate uint32 id array"
+    else:
+        pos[:, 3] = tid.view(torch.float32)
+        id_field = fl.DeviceField.from_tensor(pos, columns=(3, 4), out_dtype=np.uint32, bitcast=True)
+        layout = "HOOMD Scalar4 arrays: pos=(x,y,z,typeid bits), vel=(vx,vy,vz,mass)"
     fields = [("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
               ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
-              ("particles/typeid", fl.DeviceField.from_tensor(tid, out_dtype=np.uint32))]
+              ("particles/typeid", id_field)]
 
     path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
     f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
@@ -204,9 +215,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%d particles/GPU, position+velocity+typeid from float4/int32 HBM arrays, "
+        "config": {"workload": "%d particles/GPU, position+velocity+typeid packed from %s, "
                                "%s allgather of row counts, one shared GSD file on %s"
-                               % (N, comm_backend, args.dir),
+                               % (N, layout, comm_backend, args.dir),
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * PAYLOAD_BYTES_PER_PARTICLE,
                    "parallelism": "particle-partition x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -335,12 +335,16 @@ template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack
         {
         const uint64_t row0 = tile * TILE;
         const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
-        for (uint32_t gi = 0; gi < args.n_groups; gi++)
+        // every source array of a batch is in flight before the first byte is consumed:
+        // one load latency and two barriers per batch instead of per source array
+        for (uint32_t b = 0; b < args.n_batches; b++)
             {
-            const PackGroup& g = args.g[gi];
-            stage_rows<PACK_THREADS, VAR>(g, lds, rows, row0, tid);
+            const uint32_t g0 = args.batch_start[b], g1 = args.batch_start[b + 1];
+            for (uint32_t gi = g0; gi < g1; gi++)
+                stage_rows<PACK_THREADS, VAR>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
             __syncthreads();
-            emit_group<PACK_THREADS, MODE, VAR>(g, lds, rows, row0, tid);
+            for (uint32_t gi = g0; gi < g1; gi++)
+                emit_group<PACK_THREADS, MODE, VAR>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
             __syncthreads();
             }
         }
@@ -783,18 +787,47 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         else
             {
-            // tile: as many rows as fit the LDS budget, power of two in [16, tile_cap]
+            // tile: as many rows as the widest source row allows, power of two in [16, tile_cap]
+            size_t lds_budget = PACK_LDS_BYTES;
+            if (const char* e = getenv("PGSD_PACK_LDS_KB"))
+                lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
+            uint64_t sum_rowbytes = 0;
+            for (uint32_t k = 0; k < args.n_groups; k++)
+                sum_rowbytes += args.g[k].rowbytes;
+            // prefer a tile that lets ALL source arrays of the launch share one batch ...
             uint32_t tile = 16;
-            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * max_rowbytes <= PACK_LDS_BYTES)
+            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * sum_rowbytes <= lds_budget)
                 tile <<= 1;
+            if (tile < 256)
+                {
+                // ... unless that makes tiles tiny: then size by the widest row, several batches
+                tile = 16;
+                while (tile * 2 <= tile_cap && tile * 2 <= 512 && (uint64_t)tile * 2 * max_rowbytes <= lds_budget)
+                    tile <<= 1;
+                }
             args.tile_rows = tile;
             args.n_tiles = (N + tile - 1) / tile;
+            // batches: consecutive groups whose tiles fit the LDS budget together
+            size_t lds_bytes = 0, used = 0;
+            args.n_batches = 0;
+            args.batch_start[0] = 0;
+            for (uint32_t k = 0; k < args.n_groups; k++)
+                {
+                size_t need = ((size_t)tile * args.g[k].rowbytes + 15) & ~(size_t)15;
+                if (used != 0 && used + need > lds_budget)
+                    {
+                    args.batch_start[++args.n_batches] = (uint8_t)k;
+                    used = 0;
+                    }
+                args.g[k].lds_off = (uint32_t)used;
+                used += need;
+                lds_bytes = std::max(lds_bytes, used);
+                }
+            args.batch_start[++args.n_batches] = (uint8_t)args.n_groups;
             uint64_t blocks = args.n_tiles;
             uint64_t cap = (uint64_t)num_cus() * per_cu;
             if (blocks > cap)
                 blocks = cap;
-            size_t lds_bytes = (size_t)tile * max_rowbytes;
-            lds_bytes = (lds_bytes + 15) & ~(size_t)15;
             launch_variant(false, mode, var, (unsigned)blocks, lds_bytes, stream, args);
             }
         while (next < n_jobs && done[next])

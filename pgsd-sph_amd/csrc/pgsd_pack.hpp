@@ -16,7 +16,7 @@ enum
     {
     PACK_MAX_GROUPS = 8,       // distinct source arrays per launch
     PACK_MAX_OUT = 6,          // chunks fed from one source array
-    PACK_LDS_BYTES = 32768,    // LDS tile budget per workgroup of the workgroup-tiled kernel
+    PACK_LDS_BYTES = 40960,    // LDS budget per workgroup of the workgroup-tiled kernel (4 workgroups per CU)
     PACK_WAVE_LDS = 4096,      // private LDS window of one wavefront in the wave-streaming kernel
     PACK_MAX_ROWBYTES = 2048,  // wider source rows take the generic kernel
     PACK_MAX_M = 1024
@@ -61,6 +61,8 @@ struct PackGroup
     uint32_t n_out;
     uint32_t wave_rows;    // rows per step of one wave (multiple of 16, wave_rows*rowbytes <= PACK_WAVE_LDS)
     uint32_t direct;       // 1: single dense same-type output, chunk bytes == source bytes
+    uint32_t lds_off;      // byte offset of this group's tile inside the workgroup's LDS (tiles kernel)
+    uint32_t pad;
     PackOut out[PACK_MAX_OUT];
     };
 
@@ -70,6 +72,10 @@ struct PackArgs
     uint64_t n_tiles;
     uint32_t tile_rows;
     uint32_t n_groups;
+    // groups [batch_start[b], batch_start[b+1]) are staged together, then emitted together
+    uint32_t n_batches;
+    uint32_t pad;
+    uint8_t batch_start[PACK_MAX_GROUPS + 8];
     PackGroup g[PACK_MAX_GROUPS];
     };
 
