@@ -791,20 +791,11 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             size_t lds_budget = PACK_LDS_BYTES;
             if (const char* e = getenv("PGSD_PACK_LDS_KB"))
                 lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
-            uint64_t sum_rowbytes = 0;
-            for (uint32_t k = 0; k < args.n_groups; k++)
-                sum_rowbytes += args.g[k].rowbytes;
-            // prefer a tile that lets ALL source arrays of the launch share one batch ...
+            // tile: as many rows as the widest source row allows (power of two in [16, tile_cap]);
+            // consecutive source arrays then share a batch while their tiles fit the budget
             uint32_t tile = 16;
-            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * sum_rowbytes <= lds_budget)
+            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * max_rowbytes <= lds_budget)
                 tile <<= 1;
-            if (tile < 256)
-                {
-                // ... unless that makes tiles tiny: then size by the widest row, several batches
-                tile = 16;
-                while (tile * 2 <= tile_cap && tile * 2 <= 512 && (uint64_t)tile * 2 * max_rowbytes <= lds_budget)
-                    tile <<= 1;
-                }
             args.tile_rows = tile;
             args.n_tiles = (N + tile - 1) / tile;
             // batches: consecutive groups whose tiles fit the LDS budget together
