@@ -46,6 +46,12 @@ def make_jobs(workload, N, gen):
                 (out(N, 3, f32), np.float32, 3, vel, 0, None, False),
                 (out(N, 1, i32), np.uint32, 1, tid, 0, None, False)]
         algo, moved = 56 * N, 64 * N
+    elif workload == "hoomd_pvi":         # bench.py's layout: position+velocity+typeid, typeid in pos.w
+        pos, vel = rnd((N, 4), f32), rnd((N, 4), f32)
+        jobs = [(out(N, 3, f32), np.float32, 3, pos, 0, None, False),
+                (out(N, 1, i32), np.uint32, 1, pos, 3, None, True),
+                (out(N, 3, f32), np.float32, 3, vel, 0, None, False)]
+        algo, moved = 56 * N, 60 * N
     elif workload == "hoomd_w":           # typeid in pos.w, mass in vel.w: every byte is payload
         pos, vel = rnd((N, 4), f32), rnd((N, 4), f32)
         jobs = [(out(N, 3, f32), np.float32, 3, pos, 0, None, False),
