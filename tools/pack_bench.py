@@ -109,7 +109,7 @@ def to_c(jobs):
     return arr
 
 
-def run(workload, N, iters, warmup):
+def run(workload, N, iters, warmup, sleep_ms=0.0):
     gen = torch.Generator(device="cuda").manual_seed(1234)
     probe, algo, moved, _ = make_jobs(workload, 1024, gen)
     per_set = moved / 1024 * N
@@ -125,8 +125,12 @@ def run(workload, N, iters, warmup):
         assert _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream)) == 0, _lib.last_error()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    import time
     for i in range(iters):
         arr, n, _ = sets[i % n_sets]
+        if sleep_ms > 0:
+            torch.cuda.synchronize()
+            time.sleep(sleep_ms * 1e-3)   # let the GPU idle between launches, like a snapshot every few ms
         evs[i][0].record()
         _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
         evs[i][1].record()
@@ -144,6 +148,9 @@ if __name__ == "__main__":
     ap.add_argument("--N", type=int, default=10_000_000)
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sleep-ms", type=float, default=0.0)
     a = ap.parse_args()
     for w in a.workloads.split(","):
-        print(json.dumps(run(w, a.N, a.iters, a.warmup)), flush=True)
+        r = run(w, a.N, a.iters, a.warmup, a.sleep_ms)
+        r['sleep_ms'] = a.sleep_ms
+        print(json.dumps(r), flush=True)
