@@ -379,6 +379,45 @@ extern "C"
     int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
                          void* workspace, void* stream);
 
+    /* --- read side of the device path (restart files): file -> pinned slabs -> HBM -> unpack --- */
+
+    /* Where the rows of a chunk go in device memory (inverse of pgsd_field_desc):
+         dst[(order ? order[i] : i) * dst_stride + dst_col0 + c] = convert(chunk[row_offset + i][c])
+       converted from the chunk's type to dst_type (same rules as the pack direction; bitcast
+       needs equal element sizes).  Columns of the destination rows that no chunk writes are
+       left untouched, so position.xyz and the type id can be restored into one Scalar4 array. */
+    struct pgsd_field_dst
+        {
+        void* dst;             /* device pointer */
+        const uint32_t* order; /* device scatter index or NULL */
+        uint32_t dst_type;     /* enum pgsd_type of a destination element */
+        uint32_t dst_stride;   /* elements per destination row */
+        uint32_t dst_col0;     /* first destination column */
+        uint32_t bitcast;
+        };
+
+    /* Device twin of pgsd_read_chunk (reference pgsd.h:604-610) for a row slab: rows
+       [row_offset, row_offset + N) of `chunk` (found with pgsd_find_chunk, valid on every rank)
+       are read with pread, streamed to HBM through the pinned slab ring and unpacked by a HIP
+       kernel.  Asynchronous: complete after pgsd_device_wait_read(). Every rank reads its own
+       partition; no collective is involved. */
+    int pgsd_read_chunk_device(struct pgsd_handle* handle,
+                               const struct pgsd_index_entry* chunk,
+                               uint64_t N,
+                               uint64_t row_offset,
+                               const struct pgsd_field_dst* dst);
+    int pgsd_device_wait_read(struct pgsd_handle* handle);
+
+    /* Bare unpack kernel: dense chunk rows already in device memory -> destination arrays. */
+    struct pgsd_unpack_job
+        {
+        const void* src;   /* device pointer, N*M elements of src_type, 16-byte aligned */
+        uint32_t src_type; /* enum pgsd_type of the chunk */
+        uint32_t M;
+        struct pgsd_field_dst dst;
+        };
+    int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job* jobs, uint64_t N, void* stream);
+
     /* 1 when a gfx950-capable HIP device is visible to this process */
     int pgsd_device_available(void);
 

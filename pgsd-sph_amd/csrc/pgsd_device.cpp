@@ -22,6 +22,9 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
+#include <unistd.h>
+#include <cerrno>
 #include <mutex>
 #include <thread>
 
@@ -91,6 +94,8 @@ class DevicePipeline
             m_cv_slabs.notify_all();
             m_dispatcher.join();
             }
+        if (m_read_pool)
+            writer_pool_destroy(m_read_pool);
         if (m_pool)
             writer_pool_destroy(m_pool); // joins the writers
         (void)hipSetDevice(m_cfg.device);
@@ -203,6 +208,71 @@ class DevicePipeline
         return PGSD_SUCCESS;
         }
 
+    // ---- read side: file -> pinned slab (pread) -> HBM staging (H2D) -> unpack kernel ----
+    int read_submit(long long file_offset, size_t bytes, pgsd_unpack_job job, uint64_t N)
+        {
+        if (!m_ok)
+            return PGSD_ERROR_NO_DEVICE;
+        if (failed())
+            return PGSD_ERROR_DEVICE;
+        HIP_TRY(hipSetDevice(m_cfg.device));
+        void* stage = nullptr;
+        int rc = arena_alloc(bytes, &stage);
+        if (rc != PGSD_SUCCESS)
+            return rc;
+        job.src = stage;
+        if (!m_read_pool)
+            m_read_pool = writer_pool_create(4);
+        auto req = std::make_shared<ReadReq>();
+        req->job = job;
+        req->N = N;
+        req->pieces_left = (bytes + m_cfg.slab_bytes - 1) / m_cfg.slab_bytes;
+        HIP_TRY(hipEventCreateWithFlags(&req->all_copied, hipEventDisableTiming));
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_misc_events.push_back(req->all_copied);
+            m_reads_outstanding++;
+            }
+        for (size_t off = 0; off < bytes; off += m_cfg.slab_bytes)
+            {
+            size_t n = std::min((size_t)m_cfg.slab_bytes, bytes - off);
+            char* dst = (char*)stage + off;
+            long long foff = file_offset + (long long)off;
+            writer_pool_submit(m_read_pool, [this, req, dst, n, foff] { read_piece(req, dst, n, foff); });
+            }
+        return PGSD_SUCCESS;
+        }
+
+    int wait_read()
+        {
+        if (!m_ok)
+            return PGSD_SUCCESS;
+            {
+            std::unique_lock<std::mutex> lk(m_mutex);
+            m_cv_done.wait(lk, [this] { return m_reads_outstanding == 0; });
+            }
+        (void)hipSetDevice(m_cfg.device);
+        hipError_t e = hipStreamSynchronize(m_copy_stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(m_pack_stream);
+        if (e != hipSuccess)
+            fail(std::string("stream synchronize: ") + hipGetErrorString(e));
+        bool writes_idle;
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            writes_idle = m_outstanding == 0;
+            }
+        if (writes_idle)
+            {
+            release_events();
+            for (auto& a : m_arenas)
+                a.used = 0;
+            }
+        if (failed())
+            return m_io_error ? PGSD_ERROR_IO : PGSD_ERROR_DEVICE;
+        return PGSD_SUCCESS;
+        }
+
     void set_source_stream(void* stream)
         {
         m_source_stream = (hipStream_t)stream;
@@ -278,6 +348,13 @@ class DevicePipeline
         {
         char* base;
         size_t cap, used;
+        };
+    struct ReadReq
+        {
+        pgsd_unpack_job job;
+        uint64_t N;
+        size_t pieces_left;
+        hipEvent_t all_copied;
         };
     struct CopyJob
         {
@@ -441,6 +518,89 @@ class DevicePipeline
             }
         }
 
+    int acquire_slab()
+        {
+        std::unique_lock<std::mutex> lk(m_mutex);
+        m_cv_slabs.wait(lk, [this] { return m_stop || !m_free_slabs.empty() || !m_error.empty(); });
+        if (m_free_slabs.empty() || !m_error.empty())
+            return -1;
+        int si = (int)m_free_slabs.front();
+        m_free_slabs.pop_front();
+        return si;
+        }
+
+    void read_done()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        if (m_reads_outstanding > 0)
+            m_reads_outstanding--;
+        m_cv_done.notify_all();
+        }
+
+    void read_piece(std::shared_ptr<ReadReq> req, char* dst, size_t n, long long foff)
+        {
+        (void)hipSetDevice(m_cfg.device);
+        int si = failed() ? -1 : acquire_slab();
+        bool last = false;
+        bool ok = si >= 0;
+        if (ok)
+            {
+            Slab& s = m_slabs[(size_t)si];
+            // pread in one go; a short read means the file is shorter than its index claims
+            size_t got = 0;
+            while (got < n)
+                {
+                ssize_t r = pread(m_fd, s.host + got, n - got, (off_t)(foff + (long long)got));
+                if (r < 0 && errno == EINTR)
+                    continue;
+                if (r <= 0)
+                    break;
+                got += (size_t)r;
+                }
+            if (got != n)
+                {
+                fail("pread returned fewer bytes than the chunk holds", true);
+                ok = false;
+                }
+            }
+            {
+            std::lock_guard<std::mutex> g(m_copy_mutex);
+            if (ok)
+                {
+                Slab& s = m_slabs[(size_t)si];
+                hipError_t e = hipMemcpyAsync(dst, s.host, n, hipMemcpyHostToDevice, m_copy_stream);
+                if (e == hipSuccess)
+                    e = hipEventRecord(s.copied, m_copy_stream);
+                if (e != hipSuccess)
+                    {
+                    fail(std::string("hipMemcpyAsync H2D: ") + hipGetErrorString(e));
+                    ok = false;
+                    }
+                }
+            last = (--req->pieces_left == 0);
+            if (last && !failed())
+                {
+                // every piece of this chunk has been enqueued on the copy stream before this point
+                hipError_t e = hipEventRecord(req->all_copied, m_copy_stream);
+                if (e == hipSuccess)
+                    e = hipStreamWaitEvent(m_pack_stream, req->all_copied, 0);
+                std::string err;
+                if (e != hipSuccess)
+                    fail(std::string("read pipeline event: ") + hipGetErrorString(e));
+                else if (launch_unpack(1, &req->job, req->N, m_pack_stream, &err) != PGSD_SUCCESS)
+                    fail(err);
+                }
+            }
+        if (si >= 0)
+            {
+            if (ok)
+                (void)hipEventSynchronize(m_slabs[(size_t)si].copied);
+            release_slab(si);
+            }
+        if (last)
+            read_done();
+        }
+
     void write_piece(int si, size_t n, long long foff)
         {
         (void)hipSetDevice(m_cfg.device);
@@ -493,6 +653,9 @@ class DevicePipeline
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pack_events, m_copy_events;
     std::vector<hipEvent_t> m_misc_events;
     WriterPool* m_pool = nullptr;
+    WriterPool* m_read_pool = nullptr;
+    std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
+    size_t m_reads_outstanding = 0;
     std::thread m_dispatcher;
     std::mutex m_mutex;
     std::condition_variable m_cv_jobs, m_cv_slabs, m_cv_done;
@@ -540,6 +703,23 @@ int device_pipeline_wait_packed(DevicePipeline* p, std::string* err)
 int device_pipeline_drain(DevicePipeline* p, std::string* err)
     {
     int rc = p->drain();
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_read(DevicePipeline* p, long long file_offset, size_t bytes, const pgsd_unpack_job& job, uint64_t N,
+                         std::string* err)
+    {
+    int rc = p->read_submit(file_offset, bytes, job, N);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_wait_read(DevicePipeline* p, std::string* err)
+    {
+    int rc = p->wait_read();
     if (rc != PGSD_SUCCESS && err)
         *err = p->error();
     return rc;

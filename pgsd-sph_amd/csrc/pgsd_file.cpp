@@ -1332,6 +1332,64 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
     return rc;
     }
 
+extern "C" int pgsd_read_chunk_device(struct pgsd_handle* handle, const struct pgsd_index_entry* chunk, uint64_t N,
+                                      uint64_t row_offset, const struct pgsd_field_dst* dst)
+    {
+    // device twin of pgsd_read_chunk's all==true slab read (pgsd.c:2498-2534)
+    Impl* s = impl_of(handle);
+    if (!s || !chunk || !dst || !dst->dst)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    pgsd_index_entry c = *chunk; // a flush may move the index storage
+    if (s->flags != PGSD_OPEN_READONLY)
+        {
+        int rc = do_flush(s);
+        publish(handle, s);
+        if (rc != PGSD_SUCCESS)
+            return rc;
+        }
+    const size_t sz = sizeof_type(c.type);
+    if (sz == 0 || c.M == 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    if (N == 0)
+        return PGSD_SUCCESS;
+    if (row_offset + N > c.N)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (c.location == 0)
+        return PGSD_ERROR_FILE_CORRUPT;
+    const uint64_t rowbytes = (uint64_t)c.M * sz;
+    const long long foff = c.location + (long long)(row_offset * rowbytes);
+    const size_t bytes = (size_t)(N * rowbytes);
+    if ((uint64_t)(foff + (long long)bytes) > (uint64_t)s->file_size)
+        return PGSD_ERROR_FILE_CORRUPT;
+    int rc = ensure_device(s);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    pgsd_unpack_job job;
+    memset(&job, 0, sizeof(job));
+    job.src_type = c.type;
+    job.M = c.M;
+    job.dst = *dst;
+    std::string err;
+    rc = device_pipeline_read(s->dev, foff, bytes, job, N, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
+
+extern "C" int pgsd_device_wait_read(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!s->dev)
+        return PGSD_SUCCESS;
+    std::string err;
+    int rc = device_pipeline_wait_read(s->dev, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
+
 extern "C" int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* stream)
     {
     Impl* s = impl_of(handle);

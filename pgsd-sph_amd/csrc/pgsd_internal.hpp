@@ -57,6 +57,10 @@ void device_pipeline_destroy(DevicePipeline*);
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
 int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
 void device_pipeline_set_source_stream(DevicePipeline*, void* stream);
+// read side: rows at `file_offset` -> staging -> unpack into job.dst (job.src is filled in)
+int device_pipeline_read(DevicePipeline*, long long file_offset, size_t bytes, const pgsd_unpack_job& job, uint64_t N,
+                         std::string* err);
+int device_pipeline_wait_read(DevicePipeline*, std::string* err);
 int device_pipeline_drain(DevicePipeline*, std::string* err);
 void device_pipeline_stats(DevicePipeline*, pgsd_device_stats* out, int reset);
 bool device_pipeline_idle(DevicePipeline*);

@@ -438,6 +438,78 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_generic_kernel(const PackGe
         }
     }
 
+// ------------------------------------------------------------------ unpack (read path)
+// Inverse of the pack: a dense chunk tile (contiguous bytes) is streamed into LDS with
+// 16-byte loads; lane e then converts element e of the tile and stores it to its (row, column)
+// of the destination array.  Neighbouring lanes write neighbouring columns / rows, so a wave
+// store covers a dense span of the destination even when only 3 of 4 columns are written.
+template<int SSZ, int DSZ>
+__device__ __forceinline__ void scatter_tile(const UnpackJob& j, const char* lds, uint32_t rows, uint64_t row0)
+    {
+    const uint32_t M = j.M;
+    const uint32_t nelem = rows * M;
+    for (uint32_t e = threadIdx.x; e < nelem; e += PACK_THREADS)
+        {
+        uint32_t row = (M == 1) ? e : __umulhi(e, j.magic);
+        uint32_t col = e - row * M;
+        uint64_t raw = lds_load<SSZ>(lds + (size_t)e * SSZ);
+        uint64_t val = convert_elem<SSZ, DSZ>(raw, j.kind);
+        uint64_t drow = j.order ? (uint64_t)j.order[row0 + row] : row0 + row;
+        char* p = (char*)j.dst + (drow * j.dst_stride + j.dst_col0 + col) * DSZ;
+        if constexpr (DSZ == 8)
+            *(uint64_t*)p = val;
+        else if constexpr (DSZ == 4)
+            *(uint32_t*)p = (uint32_t)val;
+        else if constexpr (DSZ == 2)
+            *(uint16_t*)p = (uint16_t)val;
+        else
+            *(uint8_t*)p = (uint8_t)val;
+        }
+    }
+
+template<int SSZ> __device__ __forceinline__ void scatter_dispatch(const UnpackJob& j, const char* lds, uint32_t rows, uint64_t row0)
+    {
+    switch (j.dsz)
+        {
+        case 1: scatter_tile<SSZ, 1>(j, lds, rows, row0); break;
+        case 2: scatter_tile<SSZ, 2>(j, lds, rows, row0); break;
+        case 4: scatter_tile<SSZ, 4>(j, lds, rows, row0); break;
+        default: scatter_tile<SSZ, 8>(j, lds, rows, row0); break;
+        }
+    }
+
+__global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_kernel(const UnpackArgs args)
+    {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t TILE = args.tile_rows;
+    for (uint64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x)
+        {
+        const uint64_t row0 = tile * TILE;
+        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+        for (uint32_t ji = 0; ji < args.n_jobs; ji++)
+            {
+            const UnpackJob& j = args.j[ji];
+            const char* gsrc = (const char*)j.src + row0 * j.rowbytes;
+            const uint32_t nbytes = rows * j.rowbytes;
+            const uint32_t nvec = nbytes >> 4;
+            for (uint32_t v = tid; v < nvec; v += PACK_THREADS)
+                ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+            for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
+                lds[b] = gsrc[b];
+            __syncthreads();
+            switch (j.ssz)
+                {
+                case 1: scatter_dispatch<1>(j, lds, rows, row0); break;
+                case 2: scatter_dispatch<2>(j, lds, rows, row0); break;
+                case 4: scatter_dispatch<4>(j, lds, rows, row0); break;
+                default: scatter_dispatch<8>(j, lds, rows, row0); break;
+                }
+            __syncthreads();
+            }
+        }
+    }
+
 // ------------------------------------------------------------------ select (compaction)
 #define SEL_THREADS 256
 #define SEL_PER_THREAD 16
@@ -835,9 +907,88 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         }
     return PGSD_SUCCESS;
     }
+int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
+    {
+    if (n_jobs == 0 || N == 0)
+        return PGSD_SUCCESS;
+    for (uint32_t first = 0; first < n_jobs; first += UNPACK_MAX_JOBS)
+        {
+        UnpackArgs args;
+        memset(&args, 0, sizeof(args));
+        args.N = N;
+        uint32_t max_rowbytes = 0;
+        for (uint32_t i = first; i < n_jobs && i < first + UNPACK_MAX_JOBS; i++)
+            {
+            const pgsd_unpack_job& q = jobs[i];
+            const uint32_t ssz = (uint32_t)sizeof_type(q.src_type), dsz = (uint32_t)sizeof_type(q.dst.dst_type);
+            const bool s_int = q.src_type <= PGSD_TYPE_INT64, d_int = q.dst.dst_type <= PGSD_TYPE_INT64;
+            bool ok = q.src && q.dst.dst && ssz && dsz && q.M && q.M <= PACK_MAX_M
+                      && q.dst.dst_col0 + q.M <= q.dst.dst_stride && (((uintptr_t)q.src) & 15) == 0
+                      && (((uintptr_t)q.dst.dst) & (dsz - 1)) == 0 && (uint64_t)q.M * ssz <= PACK_MAX_ROWBYTES;
+            if (q.dst.bitcast)
+                ok = ok && ssz == dsz;
+            else
+                ok = ok && !(!s_int && d_int) && !(s_int && !d_int && ssz == 8);
+            if (!ok)
+                {
+                if (err)
+                    *err = "invalid unpack job (types, columns, alignment or pointers)";
+                return PGSD_ERROR_INVALID_ARGUMENT;
+                }
+            UnpackJob& j = args.j[args.n_jobs++];
+            j.src = q.src;
+            j.dst = q.dst.dst;
+            j.order = q.dst.order;
+            j.M = q.M;
+            j.ssz = ssz;
+            j.dsz = dsz;
+            j.kind = conv_kind(q.src_type, q.dst.dst_type, q.dst.bitcast);
+            j.dst_stride = q.dst.dst_stride;
+            j.dst_col0 = q.dst.dst_col0;
+            j.magic = q.M == 1 ? 0u : (uint32_t)(((1ull << 32) + q.M - 1) / q.M);
+            j.rowbytes = q.M * ssz;
+            max_rowbytes = std::max(max_rowbytes, j.rowbytes);
+            }
+        uint32_t tile = 16;
+        while (tile * 2 <= 1024 && (uint64_t)tile * 2 * max_rowbytes <= 32768)
+            tile <<= 1;
+        args.tile_rows = tile;
+        args.n_tiles = (N + tile - 1) / tile;
+        uint64_t blocks = args.n_tiles;
+        uint64_t cap = (uint64_t)num_cus() * 4;
+        if (blocks > cap)
+            blocks = cap;
+        size_t lds_bytes = ((size_t)tile * max_rowbytes + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(unpack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+        }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        {
+        if (err)
+            *err = std::string("unpack kernel launch failed: ") + hipGetErrorString(e);
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
     } // namespace pgsd_amd
 
 using namespace pgsd_amd;
+
+extern "C" int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job* jobs, uint64_t N, void* stream)
+    {
+    if (n_jobs > 0 && !jobs)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_unpack_fields: no HIP device visible (the HIP path has no CPU fallback)");
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    std::string err;
+    int rc = launch_unpack(n_jobs, jobs, N, (hipStream_t)stream, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
 
 extern "C" int pgsd_device_available(void)
     {

@@ -88,6 +88,32 @@ struct PackGenericArgs
     uint32_t M, stride, col0, ssz, dsz, kind;
     };
 
+enum
+    {
+    UNPACK_MAX_JOBS = 12
+    };
+
+struct UnpackJob
+    {
+    const void* src;       // dense chunk rows
+    void* dst;             // destination array
+    const uint32_t* order; // scatter index or nullptr
+    uint32_t M, ssz, dsz, kind;
+    uint32_t dst_stride, dst_col0, magic, rowbytes; // rowbytes = M * ssz
+    };
+
+struct UnpackArgs
+    {
+    uint64_t N;
+    uint64_t n_tiles;
+    uint32_t tile_rows;
+    uint32_t n_jobs;
+    UnpackJob j[UNPACK_MAX_JOBS];
+    };
+
+// Enqueue the unpack of `n_jobs` chunks of N rows each on `stream`. Returns a pgsd_error.
+int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
+
 // Enqueue the pack of `n_jobs` fields of N rows each on `stream`. Returns a pgsd_error.
 int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
 

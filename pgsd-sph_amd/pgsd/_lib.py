@@ -94,6 +94,15 @@ class PackJob(ctypes.Structure):
     _fields_ = [("dst", c_vp), ("dst_type", c_u32), ("M", c_u32), ("src", FieldDesc)]
 
 
+class FieldDst(ctypes.Structure):
+    _fields_ = [("dst", c_vp), ("order", c_vp), ("dst_type", c_u32), ("dst_stride", c_u32),
+                ("dst_col0", c_u32), ("bitcast", c_u32)]
+
+
+class UnpackJob(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("src_type", c_u32), ("M", c_u32), ("dst", FieldDst)]
+
+
 class DeviceConfig(ctypes.Structure):
     _fields_ = [("device", c_i32), ("slab_bytes", c_u64), ("n_slabs", c_u32), ("n_writers", c_u32),
                 ("profile", c_u32), ("reserved", c_u32)]
@@ -166,6 +175,9 @@ _sig("pgsd_device_set_source_stream", c_i32, HP, c_vp)
 _sig("pgsd_device_configure", c_i32, HP, ctypes.POINTER(DeviceConfig))
 _sig("pgsd_device_get_stats", c_i32, HP, ctypes.POINTER(DeviceStats), c_i32)
 _sig("pgsd_pack_fields", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp)
+_sig("pgsd_unpack_fields", c_i32, c_u32, ctypes.POINTER(UnpackJob), c_u64, c_vp)
+_sig("pgsd_read_chunk_device", c_i32, HP, ctypes.POINTER(IndexEntry), c_u64, c_u64, ctypes.POINTER(FieldDst))
+_sig("pgsd_device_wait_read", c_i32, HP)
 _sig("pgsd_select_workspace_bytes", ctypes.c_size_t, c_u64)
 _sig("pgsd_select_rows", c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp)
 _sig("pgsd_device_available", c_i32)

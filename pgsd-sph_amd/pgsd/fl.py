@@ -433,6 +433,81 @@ class PGSDFile(object):
             return data_array.reshape([eN])
         return data_array
 
+    def read_chunk_device(self, frame, name, out=None, N=None, offset=0, columns=None, order=None,
+                          bitcast=False, wait=True):
+        """Read rows ``[offset, offset + N)`` of a chunk straight into GPU memory.
+
+        The rows are ``pread`` into pinned slabs, copied to HBM and unpacked by a HIP kernel
+        (device twin of :meth:`read_chunk` with ``r_all=True``; every rank reads its own
+        partition).
+
+        Args:
+            frame (int), name (str): the chunk.
+            out: destination torch GPU tensor of shape ``(N,)``, ``(N, M)`` or wider ``(N, S)``
+                (e.g. a ``Scalar4`` array); ``None`` allocates a dense ``(N, M)`` tensor of the
+                chunk's type on the current device.
+            N (int): number of rows (default: all rows after ``offset``).
+            offset (int): first row.
+            columns (tuple): ``(c0, c1)`` columns of ``out`` that receive the chunk's M columns.
+            order: optional int32 GPU tensor; row ``i`` goes to ``out[order[i]]``.
+            bitcast (bool): reinterpret equal-sized elements (uint32 type id -> float ``w`` slot).
+            wait (bool): block until the data is in ``out`` (else call :meth:`wait_read`).
+
+        Returns:
+            the destination tensor.
+        """
+        self._check_open()
+        import torch
+        e = lib.pgsd_find_chunk(self._h(), int(frame), name.encode('utf-8'))
+        if not e:
+            raise KeyError("frame " + str(frame) + " / chunk " + name + " not found in: " + self.__name)
+        entry = e.contents
+        eN, eM, etype = int(entry.N), int(entry.M), int(entry.type)
+        if etype not in _PGSD_TO_NP:
+            raise ValueError("invalid type for chunk: " + name)
+        if N is None:
+            N = eN - int(offset)
+        if N < 0 or int(offset) + N > eN:
+            raise ValueError("row range outside the chunk: " + name)
+        np_dt = _PGSD_TO_NP[etype]
+        if out is None:
+            tdt = getattr(torch, np_dt.name)
+            out = torch.empty((N, eM) if eM > 1 else (N,), dtype=tdt, device='cuda')
+        if not _is_device_tensor(out):
+            raise ValueError("out must be a torch GPU tensor")
+        t2 = out.unsqueeze(1) if out.dim() == 1 else out
+        if t2.dim() != 2 or (t2.shape[1] > 1 and t2.stride(1) != 1):
+            raise ValueError("out must be 1-D or row-major 2-D")
+        stride = int(t2.stride(0)) if t2.shape[0] > 1 else int(t2.shape[1])
+        c0 = 0 if columns is None else int(columns[0])
+        if columns is not None and int(columns[1]) - c0 != eM:
+            raise ValueError("columns must span the chunk's %d columns" % eM)
+        if c0 + eM > max(stride, int(t2.shape[1])):
+            raise ValueError("chunk does not fit the destination rows")
+        if order is None and int(t2.shape[0]) < N:
+            raise ValueError("destination has fewer rows than requested")
+        dst = _lib.FieldDst()
+        dst.dst = t2.data_ptr()
+        dst.order = order.data_ptr() if order is not None else None
+        dst.dst_type = _pgsd_type(t2.dtype, name)
+        dst.dst_stride = stride
+        dst.dst_col0 = c0
+        dst.bitcast = 1 if bitcast else 0
+        self.__keepalive.append((out, order))
+        retval = lib.pgsd_read_chunk_device(self._h(), e, int(N), int(offset), ctypes.byref(dst))
+        _raise_on_error(retval, self.__name)
+        if wait:
+            self.wait_read()
+        return out
+
+    def wait_read(self):
+        """Block until every :meth:`read_chunk_device` issued so far has landed in GPU memory."""
+        self._check_open()
+        retval = lib.pgsd_device_wait_read(self._h())
+        if self.__mode == 'r':
+            self.__keepalive = []
+        _raise_on_error(retval, self.__name)
+
     def find_matching_chunk_names(self, match, write_all=False):
         """All chunk names in the file that start with ``match`` (fl.pyx:876-945)."""
         self._check_open()

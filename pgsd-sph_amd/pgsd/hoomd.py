@@ -537,6 +537,105 @@ class HOOMDTrajectory(object):
             self._initial_frame = snap
         return snap
 
+    def read_frame_device(self, idx, part=None, scalar4=False):
+        """Read frame ``idx`` with the per-particle arrays of THIS rank's partition in GPU memory.
+
+        Restart path (BASELINE config 5): each rank reads rows ``[row0, row0 + n)`` of every
+        per-particle chunk through :meth:`pgsd.fl.PGSDFile.read_chunk_device` (pread -> pinned
+        slabs -> HBM -> HIP unpack); configuration, types and log stay small host values.  Chunks
+        missing in the frame come from frame 0 or from the defaults, like :meth:`_read_frame`.
+
+        Args:
+            idx (int): frame index.
+            part (tuple): ``(row0, n)``; default: the particles split evenly over the ranks of the
+                installed communicator.
+            scalar4 (bool): also assemble HOOMD-style arrays on the device:
+                ``frame.particles.pos4 = (x, y, z, typeid bits)`` and ``vel4 = (vx, vy, vz, mass)``.
+
+        Returns:
+            `Frame` whose ``particles.N`` is this rank's count, ``particles.N_global`` the total.
+        """
+        import torch
+        if idx < 0:
+            idx += len(self)
+        if idx >= len(self) or idx < 0:
+            raise IndexError()
+        f = self.file
+        snap = Frame()
+        self._read_scalar_any(idx, 'configuration/step', snap.configuration, 'step')
+        self._read_scalar_any(idx, 'configuration/dimensions', snap.configuration, 'dimensions')
+        box_frame = idx if f.chunk_exists(idx, 'configuration/box') else (0 if f.chunk_exists(0, 'configuration/box') else None)
+        snap.configuration.box = f.read_chunk(box_frame, 'configuration/box') if box_frame is not None \
+            else snap.configuration._default_value['box']
+
+        def frame_of(chunk):
+            if f.chunk_exists(idx, chunk):
+                return idx
+            if f.chunk_exists(0, chunk):
+                return 0
+            return None
+
+        fn = frame_of('particles/N')
+        n_global = int(f.read_chunk(fn, 'particles/N')[0]) if fn is not None else 0
+        ft = frame_of('particles/types')
+        if ft is not None:
+            tmp = f.read_chunk(ft, 'particles/types')
+            tmp = tmp.view(dtype=numpy.dtype((bytes, tmp.shape[1]))).reshape([tmp.shape[0]])
+            snap.particles.types = list(a.decode('UTF-8') for a in tmp)
+        else:
+            snap.particles.types = snap.particles._default_value['types']
+
+        if part is None:
+            rank, size = self._comm()
+            base, rem = divmod(n_global, size)
+            n = base + (1 if rank < rem else 0)
+            row0 = rank * base + min(rank, rem)
+        else:
+            row0, n = int(part[0]), int(part[1])
+        snap.particles.N = n
+        snap.particles.N_global = n_global
+        snap.part = (row0, n)
+
+        specs = list(_PARTICLE_SPEC.items()) + list(_PARTICLE_SPEC_EXTRA.items())
+        for name, (dt, M) in specs:
+            chunk = 'particles/' + name
+            fr = frame_of(chunk)
+            if fr is not None and int(f.read_chunk(fr, 'particles/N')[0] if f.chunk_exists(fr, 'particles/N') else n_global) == n_global:
+                setattr(snap.particles, name, f.read_chunk_device(fr, chunk, N=n, offset=row0, wait=False))
+            elif name in snap.particles._default_value:
+                default = numpy.asarray(snap.particles._default_value[name])
+                t = torch.empty((n, M) if M > 1 else (n,), dtype=getattr(torch, numpy.dtype(dt).name), device='cuda')
+                t[...] = torch.as_tensor(default.astype(dt)).to(t.device)
+                setattr(snap.particles, name, t)
+        if scalar4 and n >= 0:
+            pos4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
+            vel4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
+            for chunk, arr, cols, bc in (('particles/position', pos4, (0, 3), False),
+                                         ('particles/typeid', pos4, (3, 4), True),
+                                         ('particles/velocity', vel4, (0, 3), False),
+                                         ('particles/mass', vel4, (3, 4), False)):
+                fr = frame_of(chunk)
+                if fr is not None:
+                    f.read_chunk_device(fr, chunk, out=arr, N=n, offset=row0, columns=cols, bitcast=bc, wait=False)
+                elif chunk == 'particles/mass':
+                    vel4[:, 3] = 1.0
+            snap.particles.pos4, snap.particles.vel4 = pos4, vel4
+        f.wait_read()
+        for log in f.find_matching_chunk_names('log/', False):
+            fr = frame_of(log)
+            if fr is not None:
+                snap.log[log[4:]] = f.read_chunk(fr, log)
+        return snap
+
+    def _read_scalar_any(self, idx, chunk, container, attr):
+        f = self.file
+        if f.chunk_exists(idx, chunk):
+            setattr(container, attr, f.read_chunk(idx, chunk)[0])
+        elif f.chunk_exists(0, chunk):
+            setattr(container, attr, f.read_chunk(0, chunk)[0])
+        else:
+            setattr(container, attr, container._default_value[attr])
+
     def __getitem__(self, key):
         """Index trajectory frames (int, negative int or slice, like a list)."""
         if isinstance(key, slice):

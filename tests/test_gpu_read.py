@@ -1,0 +1,177 @@
+"""Read path on the GPU (BASELINE config 5): file -> pinned slabs -> HBM -> HIP unpack, against
+the pure-Python reader (pgsd.pypgsd) on the same file. Bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def unpack(src_np, dst_t, M, col0=0, order=None, bitcast=False, N=None):
+    from pgsd import _lib
+    src = dev(src_np.view(np.uint8).reshape(-1))
+    job = (_lib.UnpackJob * 1)()
+    job[0].src = src.data_ptr()
+    job[0].src_type = G.type_id(src_np.dtype)
+    job[0].M = M
+    job[0].dst.dst = dst_t.data_ptr()
+    job[0].dst.order = order.data_ptr() if order is not None else None
+    job[0].dst.dst_type = G.type_id(str(dst_t.dtype)[6:])
+    job[0].dst.dst_stride = dst_t.shape[1] if dst_t.dim() == 2 else 1
+    job[0].dst.dst_col0 = col0
+    job[0].dst.bitcast = 1 if bitcast else 0
+    torch.cuda.synchronize()
+    rc = _lib.lib.pgsd_unpack_fields(1, job, N if N is not None else src_np.shape[0], None)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N", [1, 63, 1000, 1025, 70001])
+def test_unpack_float3_and_typeid_into_scalar4(N):
+    rng = np.random.default_rng(N)
+    pos = G.rand_array(rng, (N, 3), np.float32)
+    tid = rng.integers(0, 9, size=(N, 1)).astype(np.uint32)
+    pos4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    unpack(pos, pos4, 3)
+    got = pos4.cpu().numpy()
+    assert got[:, :3].tobytes() == pos.tobytes() and (got[:, 3] == 7.5).all()   # w untouched
+    unpack(tid, pos4, 1, col0=3, bitcast=True)
+    got = pos4.cpu().numpy()
+    assert got[:, :3].tobytes() == pos.tobytes()
+    assert (got[:, 3].view(np.uint32) == tid[:, 0]).all()
+
+
+@pytest.mark.parametrize("sdt,ddt", [("float32", "float64"), ("float64", "float32"), ("int32", "int64"),
+                                     ("uint8", "uint32"), ("int16", "float32"), ("uint32", "float64"),
+                                     ("int64", "int32"), ("float32", "float32"), ("uint16", "uint16")])
+def test_unpack_conversions(sdt, ddt):
+    N, M, S, c0 = 4099, 3, 5, 1
+    rng = np.random.default_rng(abs(hash((sdt, ddt))) % 2 ** 32)
+    src = G.rand_array(rng, (N, M), sdt)
+    dst = torch.zeros((N, S * np.dtype(ddt).itemsize), dtype=torch.uint8, device="cuda")
+    from pgsd import _lib
+    dsrc = dev(src.view(np.uint8).reshape(-1))
+    job = (_lib.UnpackJob * 1)()
+    job[0].src = dsrc.data_ptr()
+    job[0].src_type = G.type_id(sdt)
+    job[0].M = M
+    job[0].dst.dst = dst.data_ptr()
+    job[0].dst.dst_type = G.type_id(ddt)
+    job[0].dst.dst_stride = S
+    job[0].dst.dst_col0 = c0
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_unpack_fields(1, job, N, None) == 0
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().view(ddt).reshape(N, S)
+    expect = G.oracle_pack(src, M, out_dtype=ddt)          # same element conversion rules
+    assert got[:, c0:c0 + M].tobytes() == expect.tobytes()
+    assert (got[:, :c0] == 0).all() and (got[:, c0 + M:] == 0).all()
+
+
+def test_unpack_scatter_in_tag_order():
+    N = 5000
+    rng = np.random.default_rng(3)
+    src = G.rand_array(rng, (N, 3), np.float32)
+    order = rng.permutation(N).astype(np.int32)
+    dst = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    unpack(src, dst, 3, order=dev(order))
+    got = dst.cpu().numpy()
+    assert got[order, :3].tobytes() == src.tobytes()
+
+
+def _write_file(path, N, frames=2):
+    import pgsd.fl as fl
+    rng = np.random.default_rng(17)
+    data = []
+    with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        for i in range(frames):
+            d = {'particles/position': G.rand_array(rng, (N, 3), np.float32),
+                 'particles/velocity': G.rand_array(rng, (N, 3), np.float32),
+                 'particles/typeid': rng.integers(0, 4, size=N).astype(np.uint32),
+                 'particles/mass': (rng.random(N) + 0.5).astype(np.float32),
+                 'particles/image': rng.integers(-2, 3, size=(N, 3)).astype(np.int32)}
+            f.write_chunk('configuration/step', np.array([10 * i], dtype=np.uint64))
+            f.write_chunk('particles/N', np.array([N], dtype=np.uint32))
+            for k, v in d.items():
+                f.write_chunk(k, v)
+            f.end_frame()
+            data.append(d)
+    return data
+
+
+@pytest.mark.parametrize("N", [1, 1000, 300_007])
+def test_read_chunk_device_matches_python_reader(N, tmp_gsd):
+    import pgsd.fl as fl
+    import pgsd.pypgsd as pypgsd
+    _write_file(tmp_gsd, N)
+    ref = pypgsd.PGSDFile(open(tmp_gsd, 'rb'))
+    with fl.open(tmp_gsd, 'r') as f:
+        f.configure_device(slab_bytes=64 * 1024, n_slabs=4)      # many pieces per chunk
+        for frame in (0, 1):
+            for name in ('particles/position', 'particles/typeid', 'particles/image', 'particles/mass'):
+                got = f.read_chunk_device(frame, name)
+                exp = ref.read_chunk(frame, name)
+                assert tuple(got.shape) == exp.shape
+                assert got.cpu().numpy().tobytes() == exp.tobytes(), (frame, name)
+        # a rank's partition, into a Scalar4 array, typeid into w
+        row0, n = N // 3, N - N // 3
+        pos4 = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        f.read_chunk_device(1, 'particles/position', out=pos4, N=n, offset=row0, columns=(0, 3), wait=False)
+        f.read_chunk_device(1, 'particles/typeid', out=pos4, N=n, offset=row0, columns=(3, 4), bitcast=True, wait=False)
+        f.wait_read()
+        got = pos4.cpu().numpy()
+        assert got[:, :3].tobytes() == ref.read_chunk(1, 'particles/position').reshape(N, 3)[row0:].tobytes()
+        assert (got[:, 3].view(np.uint32) == ref.read_chunk(1, 'particles/typeid')[row0:]).all()
+        # f32 chunk into a double-precision array (Scalar = double builds)
+        pos_d = torch.zeros((N, 4), dtype=torch.float64, device="cuda")
+        f.read_chunk_device(0, 'particles/position', out=pos_d, columns=(0, 3))
+        assert (pos_d.cpu().numpy()[:, :3] == ref.read_chunk(0, 'particles/position').reshape(N, 3).astype(np.float64)).all()
+        with pytest.raises(KeyError):
+            f.read_chunk_device(0, 'particles/nope')
+        with pytest.raises(ValueError):
+            f.read_chunk_device(0, 'particles/position', N=N + 1)
+    ref.close()
+
+
+def test_hoomd_read_frame_device_round_trip(tmp_gsd):
+    """write from the GPU, read back to the GPU (partition + Scalar4 assembly)."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    N = 50_001
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pos4 = torch.randn((N, 4), generator=g, device="cuda")
+    vel4 = torch.randn((N, 4), generator=g, device="cuda")
+    tid = torch.randint(0, 5, (N,), generator=g, device="cuda", dtype=torch.int32)
+    pos4[:, 3] = tid.view(torch.float32)
+    with hoomd.open(tmp_gsd, 'w') as t:
+        fr = hoomd.Frame()
+        fr.configuration.step = 123
+        fr.configuration.box = [9, 9, 9, 0, 0, 0]
+        fr.particles.N = N
+        fr.particles.types = ['a', 'b', 'c', 'd', 'e']
+        fr.particles.position = fl.DeviceField.from_tensor(pos4, columns=(0, 3))
+        fr.particles.typeid = fl.DeviceField.from_tensor(pos4, columns=(3, 4), out_dtype=np.uint32, bitcast=True)
+        fr.particles.velocity = fl.DeviceField.from_tensor(vel4, columns=(0, 3))
+        fr.particles.mass = fl.DeviceField.from_tensor(vel4, columns=(3, 4))
+        t.append(fr)
+    with hoomd.open(tmp_gsd, 'r') as t:
+        s = t.read_frame_device(0, scalar4=True)
+        assert s.configuration.step == 123 and s.particles.N == N and s.particles.N_global == N
+        assert s.particles.types == ['a', 'b', 'c', 'd', 'e']
+        assert torch.equal(s.particles.pos4.view(torch.int32), pos4.view(torch.int32))
+        assert torch.equal(s.particles.vel4.view(torch.int32), vel4.view(torch.int32))
+        assert torch.equal(s.particles.position, pos4[:, :3].contiguous())
+        assert torch.equal(s.particles.typeid.view(torch.int32), tid)
+        assert float(s.particles.density.abs().sum()) == 0.0          # default
+        part = t.read_frame_device(0, part=(100, 777))
+        assert part.particles.N == 777
+        assert torch.equal(part.particles.velocity, vel4[100:877, :3].contiguous())
