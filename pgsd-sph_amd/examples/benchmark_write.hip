@@ -1,0 +1,120 @@
+// benchmark_write.hip -- native (no Python, no torch) harness of the device write path.
+//
+// The counterpart of the reference's pgsd/scripts/benchmark-write.cc for this library: every
+// rank (one process per GPU; ranks meet through the shm communicator or stay alone) holds
+// HOOMD-style Scalar4 arrays in HBM, and per frame calls
+//   pgsd_partition_rows  -> row offsets (the MPI_Allgather of benchmark-write.cc:39-45)
+//   pgsd_write_chunk     -> configuration/step (replicated small chunk)
+//   pgsd_write_chunks_device -> position, velocity, typeid in one fused pack launch
+//   pgsd_end_frame
+// and prints MB/s the way the reference's benchmark does, as one JSON line on rank 0.
+//
+//   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file]
+#include "pgsd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <vector>
+
+__global__ void fill_scalar4(float4* pos, float4* vel, uint64_t n, uint64_t row0)
+    {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    uint64_t g = row0 + i;
+    float x = (float)(g % 1000) * 0.1f - 50.f;
+    pos[i] = make_float4(x, x * 0.5f, -x, __uint_as_float((uint32_t)(g % 5))); // w = type id bits
+    vel[i] = make_float4(0.001f * (float)(g % 77), 1.f, -1.f, 2.5f);             // w = mass
+    }
+
+#define CHECK(x)                                                                     \
+    do                                                                               \
+        {                                                                            \
+        int rc_ = (x);                                                               \
+        if (rc_ != 0)                                                                \
+            {                                                                        \
+            fprintf(stderr, "%s failed: %d (%s)\n", #x, rc_, pgsd_last_error_string()); \
+            return 1;                                                                \
+            }                                                                        \
+        } while (0)
+
+int main(int argc, char** argv)
+    {
+    const uint64_t n = argc > 1 ? strtoull(argv[1], NULL, 10) : 10000000ull;
+    const int frames = argc > 2 ? atoi(argv[2]) : 10;
+    const char* path = argc > 3 ? argv[3] : "/dev/shm/pgsd_benchmark_write.gsd";
+    CHECK(pgsd_comm_init_from_env());
+    const int rank = pgsd_comm_rank(), P = pgsd_comm_size();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        {
+        fprintf(stderr, "no GPU\n");
+        return 1;
+        }
+    (void)hipSetDevice(rank % ndev);
+
+    uint64_t row0, n_global;
+    std::vector<uint64_t> counts((size_t)P);
+    CHECK(pgsd_partition_rows(n, &row0, &n_global, counts.data()));
+    float4 *pos, *vel;
+    (void)hipMalloc((void**)&pos, n * sizeof(float4));
+    (void)hipMalloc((void**)&vel, n * sizeof(float4));
+    hipLaunchKernelGGL(fill_scalar4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, pos, vel, n, row0);
+    (void)hipDeviceSynchronize();
+
+    struct pgsd_handle h;
+    CHECK(pgsd_create_and_open(&h, path, "benchmark_write", "hoomd", pgsd_make_version(1, 4), PGSD_OPEN_READWRITE, 0));
+    struct pgsd_chunk_req req[3];
+    memset(req, 0, sizeof(req));
+    req[0].name = "particles/position";
+    req[0].type = PGSD_TYPE_FLOAT;
+    req[0].M = 3;
+    req[0].src = {pos, NULL, PGSD_TYPE_FLOAT, 4, 0, 0};
+    req[1].name = "particles/velocity";
+    req[1].type = PGSD_TYPE_FLOAT;
+    req[1].M = 3;
+    req[1].src = {vel, NULL, PGSD_TYPE_FLOAT, 4, 0, 0};
+    req[2].name = "particles/typeid";
+    req[2].type = PGSD_TYPE_UINT32;
+    req[2].M = 1;
+    req[2].src = {pos, NULL, PGSD_TYPE_FLOAT, 4, 3, 1};
+
+    auto frame = [&](uint64_t step) -> int
+    {
+        CHECK(pgsd_partition_rows(n, &row0, &n_global, NULL));
+        CHECK(pgsd_write_chunk(&h, "configuration/step", PGSD_TYPE_UINT64, 1, 1, 1, 1, 0, 1, false, 0, &step));
+        CHECK(pgsd_write_chunks_device(&h, 3, req, n, n_global, row0));
+        CHECK(pgsd_end_frame(&h));
+        return 0;
+    };
+    if (frame(0))
+        return 1;
+    CHECK(pgsd_comm_barrier());
+    auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++)
+        if (frame((uint64_t)f + 1))
+            return 1;
+    CHECK(pgsd_comm_barrier());
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    struct pgsd_device_stats st;
+    pgsd_device_get_stats(&h, &st, 0);
+    CHECK(pgsd_close(&h));
+    if (rank == 0)
+        {
+        printf("{\"ranks\": %d, \"particles_per_rank\": %llu, \"frames\": %d, \"seconds\": %.4f, \"MBps\": %.1f, "
+               "\"pack_launches\": %llu, \"written_bytes_rank0\": %llu}\n",
+               P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
+               (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes);
+        unlink(path);
+        }
+    pgsd_comm_finalize();
+    (void)hipFree(pos);
+    (void)hipFree(vel);
+    return 0;
+    }
