@@ -20,7 +20,7 @@ def build():
     return LIB
 
 
-def run_driver(script, out_path, P, timeout=120):
+def run_driver(script, out_path, P, timeout=120, allow_fail=False):
     """Replay a scenario through the product's C ABI with P processes (shm communicator).
 
     Returns rank 0's stdout lines."""
@@ -45,6 +45,6 @@ def run_driver(script, out_path, P, timeout=120):
         except OSError:
             pass
     for r, p in enumerate(procs):
-        if p.returncode != 0:
+        if p.returncode != 0 and not (allow_fail and p.returncode == 1):
             raise RuntimeError("scenario driver rank %d exited with %s" % (r, p.returncode))
     return [ln for ln in out.decode().splitlines() if ln.strip()]

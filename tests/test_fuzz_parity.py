@@ -1,0 +1,140 @@
+"""Randomised parity: seeded random scenario scripts replayed through
+  (1) the compiled reference under mpiexec (only where oracle/_ref exists: the build container
+      and the GPU box image, which ships MPICH) -- marked `ref`,
+  (2) the CPU oracle,
+  (3) the product (same driver source linked against libpgsd_amd.so, one process per rank).
+All files and state traces must be identical.  This widens the pinning of the oracle beyond
+the 34 committed goldens and checks the product on call sequences nobody hand-picked."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import product
+import scenario as S
+
+REF_DRIVER = os.path.join(S.ROOT, "oracle", "_ref", "ref_driver")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+TYPES = ["u8", "u16", "u32", "u64", "i8", "i16", "i32", "i64", "f32", "f64"]
+NAMES = ["configuration/step", "particles/N", "particles/position", "particles/velocity", "particles/typeid",
+         "particles/image", "log/e", "a", "b/c", "x" * 70, "particles/a_rather_long_auxiliary_chunk_name_number_1",
+         "q/0", "q/1", "q/2"]
+
+
+def make_script(seed, P):
+    rng = random.Random(seed)
+    lines = ["# fuzz seed %d P %d" % (seed, P),
+             "create fuzz_app_%d hoomd %d %d %s 0" % (seed, rng.randint(0, 3), rng.randint(0, 9),
+                                                      rng.choice(["rw", "rw", "append"]))]
+    maxbuf = 64 * 1024 * 1024
+    if rng.random() < 0.35:
+        maxbuf = rng.choice([48, 64, 200, 1024, 4096])
+        lines.append("maxbuf %d" % maxbuf)
+    names = rng.sample(NAMES, rng.randint(3, len(NAMES)))
+    n_frames = rng.randint(2, 14)
+    for frame in range(n_frames):
+        lines.append("seed %d" % rng.randint(0, 10 ** 6))
+        used = set()
+        for _ in range(rng.randint(0, 9)):
+            name = rng.choice(names)
+            if name in used and rng.random() < 0.9:
+                continue
+            used.add(name)
+            t = rng.choice(TYPES)
+            M = rng.randint(1, 4)
+            if rng.random() < 0.55:
+                if rng.random() < 0.3:
+                    dist = "list:" + ",".join(str(rng.choice([0, 0, 1, 3, 17, 40])) for _ in range(P))
+                else:
+                    dist = "even:%d" % rng.randint(0, 120)
+                lines.append("chunk %s %s %d 1 %s" % (name, t, M, dist))
+            else:
+                lo = 0 if P == 1 else 1    # zero-size replicated chunks dead-lock the reference at P > 1
+                n = rng.randint(lo, 30)
+                if P > 1:
+                    # A replicated chunk >= the buffer limit takes the direct path where only rank 0
+                    # writes but file_size advances by P copies (pgsd.c:2228-2249).  If nothing is
+                    # written behind it the file ends short of its own index, the reference then
+                    # calls it corrupt on re-open -- on rank 0 only -- and dead-locks (found by this
+                    # fuzzer, seed 114).  The golden `maxbuf` scenario covers the hole itself.
+                    esz = {"8": 1, "16": 2, "32": 4, "64": 8}[t[1:]]
+                    n = max(lo, min(n, (maxbuf - 1) // (M * esz)))
+                lines.append("chunk %s %s %d 0 same:%d" % (name, t, M, n))
+            if rng.random() < 0.05:
+                lines.append("flush")
+        lines.append("end_frame")
+        r = rng.random()
+        if r < 0.25:
+            lines.append("dump")
+        elif r < 0.35 and frame > 0:
+            lines.append("find %d %s" % (rng.randint(0, frame), rng.choice(names)))
+        elif r < 0.42:
+            lines += ["close", "open %s" % rng.choice(["rw", "append"]), "dump"]
+            maxbuf = 64 * 1024 * 1024          # a fresh handle starts from the default
+            if rng.random() < 0.5:
+                maxbuf = rng.choice([64, 4096])
+                lines.append("maxbuf %d" % maxbuf)
+    lines += ["dump", "close", "open ro", "dump", "names", "find 0 %s" % names[0], "close"]
+    return "\n".join(lines) + "\n"
+
+
+def have_ref():
+    return os.path.exists(REF_DRIVER) and os.path.exists(MPIEXEC)
+
+
+CASES = [(seed, P) for seed in range(24) for P in (1, 2, 3) if (seed + P) % 3 != 1 or P == 1]
+
+
+@pytest.mark.parametrize("seed,P", CASES)
+def test_product_equals_oracle_on_random_scenarios(seed, P, tmp_path):
+    scn = tmp_path / "fuzz.scn"
+    scn.write_text(make_script(seed, P))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "product.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
+    p_log = product.run_driver(str(scn), p_path, P)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
+    assert p_log == o_log
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not have_ref(), reason="compiled reference (oracle/_ref) or MPICH not present")
+@pytest.mark.parametrize("seed,P", [(s, P) for s in range(100, 116) for P in (1, 2, 4)])
+def test_oracle_equals_compiled_reference_on_random_scenarios(seed, P, tmp_path):
+    scn = tmp_path / "fuzz.scn"
+    scn.write_text(make_script(seed, P))
+    r_path, o_path = str(tmp_path / "ref.gsd"), str(tmp_path / "oracle.gsd")
+    out = subprocess.run([MPIEXEC, "-n", str(P), REF_DRIVER, str(scn), r_path], capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()[-500:]
+    r_log = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    o_log = S.run_oracle(str(scn), o_path, P)
+    with open(r_path, "rb") as a, open(o_path, "rb") as b:
+        assert a.read() == b.read()
+    assert o_log == r_log
+
+
+def test_file_the_reference_leaves_short_is_reported_not_hung(tmp_path):
+    """Seed 114 of the fuzzer: at P=2 a replicated chunk on the direct path is the last data of
+    the session, so the file ends before the offsets its index records.  On re-open the reference
+    flags the file corrupt on rank 0 only and the other ranks wait forever (pgsd.c:1616-1639).
+    The product writes the same bytes, and on re-open EVERY rank returns PGSD_ERROR_FILE_CORRUPT
+    (-5): same verdict as the reference's rank 0 and the oracle, no dead-lock."""
+    scn = tmp_path / "short.scn"
+    scn.write_text("create app hoomd 1 4 rw 0\nmaxbuf 64\nseed 1\n"
+                   "chunk a u16 3 0 same:17\nchunk b f32 2 1 list:0,0\nend_frame\nclose\nopen rw\n")
+    o_path, p_path = str(tmp_path / "o.gsd"), str(tmp_path / "p.gsd")
+    lib = S.oracle_lib()
+    import ctypes
+    o_log = []
+    try:
+        o_log = S.run_oracle(str(scn), o_path, 2)
+    except ValueError:
+        pass
+    rc = ctypes.c_int(0)
+    assert not lib.oracle_open(o_path.encode(), 2, 1, ctypes.byref(rc)) and rc.value == -5
+    p_log = product.run_driver(str(scn), p_path, 2, allow_fail=True)
+    assert p_log == ["rc line=8 cmd=open rc=-5"]
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
