@@ -20,6 +20,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -222,7 +223,13 @@ class DevicePipeline
             return rc;
         job.src = stage;
         if (!m_read_pool)
-            m_read_pool = writer_pool_create(4);
+            {
+            // reads of the page cache take no exclusive lock and scale with threads
+            unsigned n = 8;
+            if (const char* e = getenv("PGSD_READERS"))
+                n = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : n;
+            m_read_pool = writer_pool_create(n);
+            }
         auto req = std::make_shared<ReadReq>();
         req->job = job;
         req->N = N;
