@@ -1,0 +1,29 @@
+// pgsd_device_stub.cpp -- NOT part of libpgsd_amd.so.  Link-time stand-ins for the device
+// pipeline so that the HOST file layer (pgsd_file.cpp, pgsd_comm.cpp, pgsd_io.cpp) can be built
+// with gcc -fsanitize=address,undefined and exercised by the scenario driver on a CPU box
+// (`make asan`; GPU AddressSanitizer is not available on the pool).  Every device entry point
+// fails with PGSD_ERROR_NO_DEVICE, exactly as the real library does without a GPU.
+#include "pgsd_internal.hpp"
+
+namespace pgsd_amd
+    {
+DevicePipeline* device_pipeline_create(const pgsd_device_config&, int, bool, std::string* err)
+    {
+    if (err)
+        *err = "sanitizer build: no device pipeline";
+    return nullptr;
+    }
+void device_pipeline_destroy(DevicePipeline*) { }
+int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+int device_pipeline_wait_packed(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+void device_pipeline_set_source_stream(DevicePipeline*, void*) { }
+int device_pipeline_read(DevicePipeline*, long long, size_t, const pgsd_unpack_job&, uint64_t, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+int device_pipeline_wait_read(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+int device_pipeline_drain(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+void device_pipeline_stats(DevicePipeline*, pgsd_device_stats*, int) { }
+bool device_pipeline_idle(DevicePipeline*) { return true; }
+    } // namespace pgsd_amd
+
+extern "C" int pgsd_device_available(void) { return 0; }
+extern "C" int pgsd_comm_rccl_unique_id(void*) { return PGSD_ERROR_NO_DEVICE; }
+extern "C" int pgsd_comm_init_rccl(const void*, int, int, int) { return PGSD_ERROR_NO_DEVICE; }

@@ -201,6 +201,14 @@ class PGSDFile(object):
         else:
             raise ValueError("Invalid mode: " + mode)
 
+        # One process per rank under torchrun: make sure the library knows about the other ranks
+        # (a rank that believes it is alone would overwrite its neighbours' rows).
+        if lib.pgsd_comm_size() == 1 and _lib._torch is not None:
+            tdist = _lib._torch.distributed
+            if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+                from . import dist as _dist
+                _dist.init_from_torch()
+
         self.__name = name
         self.__handle = _lib.Handle()
         self.__keepalive = []
