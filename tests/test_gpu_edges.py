@@ -1,0 +1,104 @@
+"""Edge cases of the device entry points (through pgsd.fl / the C ABI)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+import scenario as S
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_replicated_small_chunk_from_device_takes_the_buffered_path(tmp_path):
+    """write_all=False with device data: packed, copied synchronously and appended to the
+    small-chunk buffer exactly like host data (pgsd.c:2160-2202)."""
+    import pgsd.fl as fl
+    a, b = str(tmp_path / "dev.gsd"), str(tmp_path / "host.gsd")
+    box = np.array([[10, 11, 12, 0, 0, 0]], dtype=np.float64).T.copy()      # (6,1) float64 on the GPU
+    step = np.array([42], dtype=np.uint64)
+    for path, on_gpu in ((a, True), (b, False)):
+        with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+            for frame in range(3):
+                if on_gpu:
+                    f.write_chunk('configuration/box',
+                                  fl.DeviceField.from_tensor(dev(box), out_dtype=np.float32), write_all=False)
+                    f.write_chunk('configuration/step', dev(step.view(np.int64)).view(torch.int64), write_all=False)
+                else:
+                    f.write_chunk('configuration/box', box.astype(np.float32), write_all=False)
+                    f.write_chunk('configuration/step', step.view(np.int64), write_all=False)
+                f.end_frame()
+    with open(a, 'rb') as fa, open(b, 'rb') as fb:
+        assert fa.read() == fb.read()
+
+
+def test_zero_rows_and_errors(tmp_gsd):
+    import pgsd.fl as fl
+    from pgsd import _lib
+    with fl.open(tmp_gsd, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        empty = torch.zeros((0, 4), dtype=torch.float32, device="cuda")
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(empty, columns=(0, 3)))],
+                       offset=np.array([0]))
+        f.end_frame()
+        assert f.nframes == 1 and f.chunk_exists(0, 'particles/position')
+        assert f.read_chunk(0, 'particles/position').shape == (0, 3)
+        src = torch.zeros((8, 4), dtype=torch.float32, device="cuda")
+        with pytest.raises(RuntimeError, match="Invalid pgsd argument"):
+            f.write_chunk('bad', fl.DeviceField(src.data_ptr(), np.float32, 8, 5, stride=4))     # M > stride
+        with pytest.raises(RuntimeError, match="Invalid pgsd argument"):
+            f.write_chunk('bad', fl.DeviceField(src.data_ptr(), np.float32, 8, 3, stride=4, out_dtype=np.int32))
+        with pytest.raises(ValueError):
+            f.write_chunks([('a', src), ('b', torch.zeros((9, 4), device="cuda"))])
+        f.write_chunk('ok', src)
+        f.wait_packed()
+        f.end_frame()
+    with fl.open(tmp_gsd, 'r') as f:
+        src = torch.zeros((8, 4), dtype=torch.float32, device="cuda")
+        with pytest.raises(RuntimeError, match="File must be writable"):
+            f.write_chunk('nope', src)
+        assert f.read_chunk(1, 'ok').shape == (8, 4)
+
+
+def test_device_and_host_chunks_interleave_with_index_relocation(tmp_path):
+    """40 frames x 5 chunks (host and device mixed) force two on-disk index relocations while the
+    device pipeline is in use; compare with the oracle."""
+    import pgsd.fl as fl
+    N = 3001
+    rng = np.random.default_rng(8)
+    mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
+    lib = S.oracle_lib()
+    rc = ctypes.c_int(0)
+    h = lib.oracle_create_and_open(ref.encode(), 1, b'app', b'hoomd', lib.oracle_make_version(1, 4), 1, 0,
+                                   ctypes.byref(rc))
+    f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+    f.configure_device(slab_bytes=16 * 1024, n_slabs=2)
+    for frame in range(40):
+        pos4 = G.rand_array(rng, (N, 4), np.float32)
+        img = rng.integers(-1, 2, size=(N, 3)).astype(np.int32)
+        dens = G.rand_array(rng, (N,), np.float64)
+        step = np.array([frame], dtype=np.uint64)
+        dpos, ddens = dev(pos4), dev(dens)
+        f.write_chunk('configuration/step', step, write_all=False)
+        f.write_chunk('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3)), offset=np.array([N]))
+        f.write_chunk('particles/image', img, offset=np.array([N]))
+        f.write_chunks([('particles/density', fl.DeviceField.from_tensor(ddens, out_dtype=np.float32)),
+                        ('particles/w', fl.DeviceField.from_tensor(dpos, columns=(3, 4)))], offset=np.array([N]))
+        f.end_frame()
+        for name, t, M, all_, arr in (('configuration/step', 4, 1, False, step.reshape(1, 1)),
+                                      ('particles/position', 9, 3, True, np.ascontiguousarray(pos4[:, :3])),
+                                      ('particles/image', 7, 3, True, img),
+                                      ('particles/density', 9, 1, True, dens.astype(np.float32).reshape(-1, 1)),
+                                      ('particles/w', 9, 1, True, np.ascontiguousarray(pos4[:, 3:4]))):
+            n = arr.shape[0]
+            assert S.oracle_write_chunk(lib, h, name, t, [arr], M, n, M, [0], [n * M], all_) == 0
+        assert lib.oracle_end_frame(h) == 0
+    f.close()
+    assert lib.oracle_close(h) == 0
+    with open(mine, 'rb') as a, open(ref, 'rb') as b:
+        assert a.read() == b.read()
