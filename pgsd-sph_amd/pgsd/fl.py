@@ -164,6 +164,38 @@ def _is_device_tensor(x):
     return hasattr(x, 'data_ptr') and getattr(x, 'is_cuda', False)
 
 
+def select_rows(flags):
+    """Stream compaction on the GPU for filtered snapshots.
+
+    Args:
+        flags: uint8 / bool torch GPU tensor of length N; non-zero = keep the particle.
+
+    Returns:
+        ``(index, count)``: ``index`` is an int32 GPU tensor whose first ``count`` entries are the
+        kept rows in ascending order (usable as ``order=`` of :meth:`DeviceField.from_tensor`);
+        ``count`` (int) is this rank's number of rows, i.e. what goes into the row-count allgather
+        (``pgsd.dist.partition_rows``) that fixes every rank's file offsets.
+
+    Wave-level ballot/popcount scans produce per-workgroup counts, one workgroup scans them
+    into offsets, a scatter pass writes the indices (pgsd_select_rows in the C ABI).
+    """
+    import torch
+    if not _is_device_tensor(flags):
+        raise ValueError("flags must be a torch GPU tensor")
+    f8 = flags.contiguous().view(torch.uint8) if flags.dtype in (torch.bool, torch.uint8, torch.int8) \
+        else (flags != 0).to(torch.uint8)
+    n = int(f8.numel())
+    index = torch.empty((max(n, 1),), dtype=torch.int32, device=f8.device)
+    count = torch.zeros((1,), dtype=torch.int64, device=f8.device)
+    ws = torch.empty((max(int(lib.pgsd_select_workspace_bytes(n)), 16),), dtype=torch.uint8, device=f8.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    retval = lib.pgsd_select_rows(f8.data_ptr(), n, index.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                  ctypes.c_void_p(stream))
+    _raise_on_error(retval, "select_rows")
+    k = int(count.item())          # synchronises the stream
+    return index[:k], k
+
+
 def open(name, mode, application=None, schema=None, schema_version=None):
     """Open a PGSD file and return a :py:class:`PGSDFile` (fl.pyx:149-228).
 

@@ -102,3 +102,32 @@ def test_device_and_host_chunks_interleave_with_index_relocation(tmp_path):
     assert lib.oracle_close(h) == 0
     with open(mine, 'rb') as a, open(ref, 'rb') as b:
         assert a.read() == b.read()
+
+
+def test_filtered_snapshot_select_then_gather(tmp_path):
+    """A filtered snapshot: flags -> pgsd.fl.select_rows (device scan) -> count into the row-count
+    exchange -> gather-pack of the selected rows; equals the host-side boolean indexing."""
+    import pgsd.dist as pdist
+    import pgsd.fl as fl
+    N = 200_003
+    rng = np.random.default_rng(12)
+    pos4 = G.rand_array(rng, (N, 4), np.float32)
+    keep = rng.random(N) < 0.37
+    dpos, dkeep = dev(pos4), dev(keep)
+    index, k = fl.select_rows(dkeep)
+    assert k == int(keep.sum())
+    assert (index.cpu().numpy() == np.nonzero(keep)[0]).all()
+    counts, row0, n_global = pdist.partition_rows(k)
+    assert n_global == k and row0 == 0
+    path = str(tmp_path / "filtered.gsd")
+    with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        f.write_chunk('particles/N', np.array([k], dtype=np.uint32), write_all=False)
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3), order=index)),
+                        ('particles/w', fl.DeviceField.from_tensor(dpos, columns=(3, 4), order=index))],
+                       offset=counts)
+        f.end_frame()
+    with fl.open(path, 'r') as f:
+        assert f.read_chunk(0, 'particles/position').tobytes() == np.ascontiguousarray(pos4[keep, :3]).tobytes()
+        assert f.read_chunk(0, 'particles/w').tobytes() == np.ascontiguousarray(pos4[keep, 3]).tobytes()
+    none, k0 = fl.select_rows(torch.zeros(1000, dtype=torch.uint8, device="cuda"))
+    assert k0 == 0 and none.numel() == 0
