@@ -290,13 +290,42 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
         const uint32_t* ord = g.order + row0;
         if (rowbytes == 16)
             {
-            for (uint32_t i = tid; i < rows; i += NT)
+            // indices first, then four independent row fetches in flight per lane
+            uint32_t i = tid;
+            for (; i + 3 * NT < rows; i += 4 * NT)
+                {
+                const uint32_t o0 = ord[i], o1 = ord[i + NT], o2 = ord[i + 2 * NT], o3 = ord[i + 3 * NT];
+                u32x4 a = *((const u32x4*)g.src + o0);
+                u32x4 b = *((const u32x4*)g.src + o1);
+                u32x4 c = *((const u32x4*)g.src + o2);
+                u32x4 d = *((const u32x4*)g.src + o3);
+                ((u32x4*)lds)[i] = a;
+                ((u32x4*)lds)[i + NT] = b;
+                ((u32x4*)lds)[i + 2 * NT] = c;
+                ((u32x4*)lds)[i + 3 * NT] = d;
+                }
+            for (; i < rows; i += NT)
                 ((u32x4*)lds)[i] = *((const u32x4*)g.src + ord[i]);
             }
         else if (rowbytes == 32)
             {
-            for (uint32_t i = tid; i < 2 * rows; i += NT)
-                ((u32x4*)lds)[i] = *((const u32x4*)g.src + 2 * (uint64_t)ord[i >> 1] + (i & 1));
+            uint32_t i = tid;
+            for (; i + NT < rows; i += 2 * NT)
+                {
+                const uint64_t o0 = ord[i], o1 = ord[i + NT];
+                u32x4 a0 = *((const u32x4*)g.src + 2 * o0), a1 = *((const u32x4*)g.src + 2 * o0 + 1);
+                u32x4 b0 = *((const u32x4*)g.src + 2 * o1), b1 = *((const u32x4*)g.src + 2 * o1 + 1);
+                ((u32x4*)lds)[2 * i] = a0;
+                ((u32x4*)lds)[2 * i + 1] = a1;
+                ((u32x4*)lds)[2 * (i + NT)] = b0;
+                ((u32x4*)lds)[2 * (i + NT) + 1] = b1;
+                }
+            for (; i < rows; i += NT)
+                {
+                const uint64_t o0 = ord[i];
+                ((u32x4*)lds)[2 * i] = *((const u32x4*)g.src + 2 * o0);
+                ((u32x4*)lds)[2 * i + 1] = *((const u32x4*)g.src + 2 * o0 + 1);
+                }
             }
         else if ((rowbytes & 3) == 0)
             {
