@@ -131,3 +131,56 @@ def test_filtered_snapshot_select_then_gather(tmp_path):
         assert f.read_chunk(0, 'particles/w').tobytes() == np.ascontiguousarray(pos4[keep, 3]).tobytes()
     none, k0 = fl.select_rows(torch.zeros(1000, dtype=torch.uint8, device="cuda"))
     assert k0 == 0 and none.numel() == 0
+
+
+def test_pipeline_soak_random_frames(tmp_path):
+    """Stress the slab ring / event hand-offs: 120 frames of random size (including empty ones)
+    through tiny slabs and two writer threads, single and fused device writes mixed with host
+    chunks; the whole file must equal the oracle's."""
+    import pgsd.fl as fl
+    rng = np.random.default_rng(2024)
+    mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
+    lib = S.oracle_lib()
+    rc = ctypes.c_int(0)
+    h = lib.oracle_create_and_open(ref.encode(), 1, b'app', b'hoomd', lib.oracle_make_version(1, 4), 1, 0,
+                                   ctypes.byref(rc))
+    f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+    f.configure_device(slab_bytes=32 * 1024, n_slabs=3, n_writers=2)
+    for frame in range(120):
+        N = int(rng.choice([0, 1, 17, 1023, 1024, 5000, 33333, 60000]))
+        pos4 = G.rand_array(rng, (N, 4), np.float64)
+        vel4 = G.rand_array(rng, (N, 4), np.float32)
+        aux = G.rand_array(rng, (N, 3), np.float32)
+        dpos, dvel = dev(pos4), dev(vel4)
+        part = np.array([N])
+        chunks = [('configuration/step', 4, 1, False, np.array([[frame]], dtype=np.uint64))]
+        f.write_chunk('configuration/step', np.array([frame], dtype=np.uint64), write_all=False)
+        if frame % 3 == 0:
+            f.write_chunk('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3), out_dtype=np.float32),
+                          offset=part)
+            f.write_chunk('particles/auxiliary1', aux, offset=part)
+            f.write_chunk('particles/velocity', fl.DeviceField.from_tensor(dvel, columns=(0, 3)), offset=part)
+            order = ['particles/position', 'particles/auxiliary1', 'particles/velocity']
+        else:
+            f.write_chunks([('particles/velocity', fl.DeviceField.from_tensor(dvel, columns=(0, 3))),
+                            ('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3), out_dtype=np.float32))],
+                           offset=part)
+            f.write_chunk('particles/auxiliary1', aux, offset=part)
+            order = ['particles/velocity', 'particles/position', 'particles/auxiliary1']
+        data = {'particles/position': (9, 3, pos4[:, :3].astype(np.float32)),
+                'particles/velocity': (9, 3, np.ascontiguousarray(vel4[:, :3])),
+                'particles/auxiliary1': (9, 3, aux)}
+        for name in order:
+            t, M, arr = data[name]
+            chunks.append((name, t, M, True, np.ascontiguousarray(arr)))
+        f.end_frame()
+        for name, t, M, all_, arr in chunks:
+            n = arr.shape[0]
+            assert S.oracle_write_chunk(lib, h, name, t, [arr], M, n, M, [0], [n * M], all_) == 0
+        assert lib.oracle_end_frame(h) == 0
+    st = f.device_stats()
+    assert st['written_bytes'] == st['pack_bytes_out']
+    f.close()
+    assert lib.oracle_close(h) == 0
+    with open(mine, 'rb') as a, open(ref, 'rb') as b:
+        assert a.read() == b.read()
