@@ -325,12 +325,6 @@ class DevicePipeline
         return PGSD_SUCCESS;
         }
 
-    bool idle()
-        {
-        std::lock_guard<std::mutex> g(m_mutex);
-        return m_outstanding == 0;
-        }
-
     void stats(pgsd_device_stats* out, int reset)
         {
         std::lock_guard<std::mutex> g(m_mutex);
@@ -742,8 +736,4 @@ void device_pipeline_stats(DevicePipeline* p, pgsd_device_stats* out, int reset)
     p->stats(out, reset);
     }
 
-bool device_pipeline_idle(DevicePipeline* p)
-    {
-    return p->idle();
-    }
     } // namespace pgsd_amd

@@ -21,7 +21,6 @@ int device_pipeline_read(DevicePipeline*, long long, size_t, const pgsd_unpack_j
 int device_pipeline_wait_read(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_drain(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 void device_pipeline_stats(DevicePipeline*, pgsd_device_stats*, int) { }
-bool device_pipeline_idle(DevicePipeline*) { return true; }
     } // namespace pgsd_amd
 
 extern "C" int pgsd_device_available(void) { return 0; }

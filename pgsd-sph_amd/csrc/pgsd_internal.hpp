@@ -31,7 +31,6 @@ class WriterPool;
 WriterPool* writer_pool_create(unsigned n_threads);
 void writer_pool_destroy(WriterPool*);
 void writer_pool_submit(WriterPool*, std::function<void()> fn);
-unsigned writer_pool_size(WriterPool*);
 // Write [buf, buf+bytes) at `offset` of fd, split over the pool; blocks until done.
 // Returns 0 or -errno.
 int writer_pool_pwrite_sync(WriterPool*, int fd, const void* buf, size_t bytes, long long offset,
@@ -63,10 +62,8 @@ int device_pipeline_read(DevicePipeline*, long long file_offset, size_t bytes, c
 int device_pipeline_wait_read(DevicePipeline*, std::string* err);
 int device_pipeline_drain(DevicePipeline*, std::string* err);
 void device_pipeline_stats(DevicePipeline*, pgsd_device_stats* out, int reset);
-bool device_pipeline_idle(DevicePipeline*);
 
 size_t sizeof_type(uint32_t type);
-// source bytes that must be read per row for a field (algorithmic, not padded)
     } // namespace pgsd_amd
 
 #endif

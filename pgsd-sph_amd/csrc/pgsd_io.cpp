@@ -1,8 +1,10 @@
 // pgsd_io.cpp -- positional file IO standing in for the reference's MPI-IO calls
 // (MPI_File_write_at pgsd.c:2229/1154/2032, MPI_File_read_at pgsd.c:651/1559/2534).
-// Each rank writes its own byte range with pwrite at the offset the reference computes;
-// large ranges are split over a small pool of writer threads because a tmpfs / page-cache
-// write is a CPU copy and one core does not saturate host memory bandwidth.
+// Each rank writes its own byte range with pwrite at the offset the reference computes.
+// The small thread pool here carries the device pipeline's writer and reader threads.  For
+// WRITES one thread per file is the measured optimum on the target boxes (buffered writes
+// serialise on the file's inode lock: profiles/r01_io_probe*.log); page-cache READS take no
+// exclusive lock and scale with threads.
 #include "pgsd_internal.hpp"
 
 #include <cerrno>
@@ -152,11 +154,6 @@ void writer_pool_destroy(WriterPool* p)
 void writer_pool_submit(WriterPool* p, std::function<void()> fn)
     {
     p->submit(std::move(fn));
-    }
-
-unsigned writer_pool_size(WriterPool* p)
-    {
-    return p->size();
     }
 
 int writer_pool_pwrite_sync(WriterPool* pool, int fd, const void* buf, size_t bytes, long long offset,
