@@ -113,6 +113,20 @@ enum
     VAR_PLAIN_STORE = 4 // default cache policy for chunk stores instead of non-temporal
     };
 
+// LDS image skew: 16 bytes of padding after every 128 bytes.  A staged float4 tile read back
+// column-wise (position.xyz with stride 16/3 words, the w column with stride 16 words) hits the
+// same few of the 32 banks: 6-way conflicts for xyz, 16-way for w in the linear image; with the
+// skew every 8th row shifts by 4 banks and the worst cases drop to 2- and 4-way
+// (SQ_LDS_BANK_CONFLICT, profiles/).  LDS-DMA writes whole 1 KiB pieces linearly, so that
+// variant keeps the linear image.
+template<int VAR> __device__ __forceinline__ uint32_t lds_skew(uint32_t byte_off)
+    {
+    if constexpr (VAR & VAR_GLDS)
+        return byte_off;
+    else
+        return byte_off + ((byte_off >> 7) << 4);
+    }
+
 template<int VAR> __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
     {
     if constexpr (VAR & VAR_PLAIN_LOAD)
@@ -153,7 +167,7 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
 #pragma unroll
         for (uint32_t k = 0; k < EPT; k++)
             {
-            uint64_t raw = lds_load<SSZ>(lds + (size_t)(row * stride_elems + col0 + col) * SSZ);
+            uint64_t raw = lds_load<SSZ>(lds + lds_skew<VAR>((row * stride_elems + col0 + col) * SSZ));
             uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
             if constexpr (DSZ == 8)
                 {
@@ -180,7 +194,7 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
         {
         uint32_t row = (M == 1) ? e : __umulhi(e, o.magic);
         uint32_t col = e - row * M;
-        uint64_t raw = lds_load<SSZ>(lds + (size_t)(row * stride_elems + col0 + col) * SSZ);
+        uint64_t raw = lds_load<SSZ>(lds + lds_skew<VAR>((row * stride_elems + col0 + col) * SSZ));
         uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
         char* p = gdst + (size_t)e * DSZ;
         if constexpr (DSZ == 8)
@@ -273,16 +287,16 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
                 u32x4 b = stream_load<VAR>((const u32x4*)gsrc + v + NT);
                 u32x4 c = stream_load<VAR>((const u32x4*)gsrc + v + 2 * NT);
                 u32x4 d = stream_load<VAR>((const u32x4*)gsrc + v + 3 * NT);
-                ((u32x4*)lds)[v] = a;
-                ((u32x4*)lds)[v + NT] = b;
-                ((u32x4*)lds)[v + 2 * NT] = c;
-                ((u32x4*)lds)[v + 3 * NT] = d;
+                *(u32x4*)(lds + lds_skew<VAR>(v << 4)) = a;
+                *(u32x4*)(lds + lds_skew<VAR>((v + NT) << 4)) = b;
+                *(u32x4*)(lds + lds_skew<VAR>((v + 2 * NT) << 4)) = c;
+                *(u32x4*)(lds + lds_skew<VAR>((v + 3 * NT) << 4)) = d;
                 }
             for (; v < nvec; v += NT)
-                ((u32x4*)lds)[v] = stream_load<VAR>((const u32x4*)gsrc + v);
+                *(u32x4*)(lds + lds_skew<VAR>(v << 4)) = stream_load<VAR>((const u32x4*)gsrc + v);
             }
         for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += NT)
-            lds[b] = gsrc[b];
+            lds[lds_skew<VAR>(b)] = gsrc[b];
         }
     else
         {
@@ -299,13 +313,13 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
                 u32x4 b = *((const u32x4*)g.src + o1);
                 u32x4 c = *((const u32x4*)g.src + o2);
                 u32x4 d = *((const u32x4*)g.src + o3);
-                ((u32x4*)lds)[i] = a;
-                ((u32x4*)lds)[i + NT] = b;
-                ((u32x4*)lds)[i + 2 * NT] = c;
-                ((u32x4*)lds)[i + 3 * NT] = d;
+                *(u32x4*)(lds + lds_skew<VAR>(i << 4)) = a;
+                *(u32x4*)(lds + lds_skew<VAR>((i + NT) << 4)) = b;
+                *(u32x4*)(lds + lds_skew<VAR>((i + 2 * NT) << 4)) = c;
+                *(u32x4*)(lds + lds_skew<VAR>((i + 3 * NT) << 4)) = d;
                 }
             for (; i < rows; i += NT)
-                ((u32x4*)lds)[i] = *((const u32x4*)g.src + ord[i]);
+                *(u32x4*)(lds + lds_skew<VAR>(i << 4)) = *((const u32x4*)g.src + ord[i]);
             }
         else if (rowbytes == 32)
             {
@@ -315,16 +329,16 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
                 const uint64_t o0 = ord[i], o1 = ord[i + NT];
                 u32x4 a0 = *((const u32x4*)g.src + 2 * o0), a1 = *((const u32x4*)g.src + 2 * o0 + 1);
                 u32x4 b0 = *((const u32x4*)g.src + 2 * o1), b1 = *((const u32x4*)g.src + 2 * o1 + 1);
-                ((u32x4*)lds)[2 * i] = a0;
-                ((u32x4*)lds)[2 * i + 1] = a1;
-                ((u32x4*)lds)[2 * (i + NT)] = b0;
-                ((u32x4*)lds)[2 * (i + NT) + 1] = b1;
+                *(u32x4*)(lds + lds_skew<VAR>((2 * i) << 4)) = a0;
+                *(u32x4*)(lds + lds_skew<VAR>((2 * i + 1) << 4)) = a1;
+                *(u32x4*)(lds + lds_skew<VAR>((2 * (i + NT)) << 4)) = b0;
+                *(u32x4*)(lds + lds_skew<VAR>((2 * (i + NT) + 1) << 4)) = b1;
                 }
             for (; i < rows; i += NT)
                 {
                 const uint64_t o0 = ord[i];
-                ((u32x4*)lds)[2 * i] = *((const u32x4*)g.src + 2 * o0);
-                ((u32x4*)lds)[2 * i + 1] = *((const u32x4*)g.src + 2 * o0 + 1);
+                *(u32x4*)(lds + lds_skew<VAR>((2 * i) << 4)) = *((const u32x4*)g.src + 2 * o0);
+                *(u32x4*)(lds + lds_skew<VAR>((2 * i + 1) << 4)) = *((const u32x4*)g.src + 2 * o0 + 1);
                 }
             }
         else if ((rowbytes & 3) == 0)
@@ -334,7 +348,7 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
             for (uint32_t i = tid; i < nw; i += NT)
                 {
                 uint32_t r = i / wpr, c = i - r * wpr;
-                ((uint32_t*)lds)[i] = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
+                *(uint32_t*)(lds + lds_skew<VAR>(i << 2)) = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
                 }
             }
         else
@@ -343,7 +357,7 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
             for (uint32_t i = tid; i < nb; i += NT)
                 {
                 uint32_t r = i / rowbytes, c = i - r * rowbytes;
-                lds[i] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
+                lds[lds_skew<VAR>(i)] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
                 }
             }
         }
@@ -388,7 +402,7 @@ template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    char* lds = lds_all + wave * PACK_WAVE_LDS;
+    char* lds = lds_all + wave * PACK_WAVE_LDS_SKEWED;
     const uint64_t gw = (uint64_t)blockIdx.x * (PACK_THREADS / 64) + wave;
     const uint64_t nw = (uint64_t)gridDim.x * (PACK_THREADS / 64);
 
@@ -884,7 +898,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t max_blocks = (N + 255) / 256;
             if (blocks > max_blocks)
                 blocks = max_blocks;
-            launch_variant(true, mode, var, (unsigned)blocks, (PACK_THREADS / 64) * PACK_WAVE_LDS, stream, args);
+            launch_variant(true, mode, var, (unsigned)blocks, (PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, stream, args);
             }
         else
             {
@@ -905,7 +919,8 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             args.batch_start[0] = 0;
             for (uint32_t k = 0; k < args.n_groups; k++)
                 {
-                size_t need = ((size_t)tile * args.g[k].rowbytes + 15) & ~(size_t)15;
+                size_t lin = (size_t)tile * args.g[k].rowbytes;
+                size_t need = (lin + ((lin >> 7) << 4) + 31) & ~(size_t)15; // skewed image (lds_skew)
                 if (used != 0 && used + need > lds_budget)
                     {
                     args.batch_start[++args.n_batches] = (uint8_t)k;

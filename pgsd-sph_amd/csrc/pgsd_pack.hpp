@@ -16,8 +16,9 @@ enum
     {
     PACK_MAX_GROUPS = 8,       // distinct source arrays per launch
     PACK_MAX_OUT = 6,          // chunks fed from one source array
-    PACK_LDS_BYTES = 40960,    // LDS budget per workgroup of the workgroup-tiled kernel (4 workgroups per CU)
+    PACK_LDS_BYTES = 49152,    // LDS budget per workgroup of the workgroup-tiled kernel (3 workgroups per CU)
     PACK_WAVE_LDS = 4096,      // private LDS window of one wavefront in the wave-streaming kernel
+    PACK_WAVE_LDS_SKEWED = 4096 + 4096 / 8 + 16, // the same window with the bank skew applied
     PACK_MAX_ROWBYTES = 2048,  // wider source rows take the generic kernel
     PACK_MAX_M = 1024
     };
