@@ -110,7 +110,8 @@ enum
     {
     VAR_GLDS = 1,       // stage linear tiles with LDS-DMA (global_load_lds_dwordx4) instead of VGPRs
     VAR_PLAIN_LOAD = 2, // default cache policy for source loads instead of non-temporal
-    VAR_PLAIN_STORE = 4 // default cache policy for chunk stores instead of non-temporal
+    VAR_PLAIN_STORE = 4, // default cache policy for chunk stores instead of non-temporal
+    VAR_LINEAR_LDS = 8   // no bank skew in the LDS image (A/B switch for the sweeps)
     };
 
 // LDS image skew: 16 bytes of padding after every 128 bytes.  A staged float4 tile read back
@@ -121,7 +122,7 @@ enum
 // variant keeps the linear image.
 template<int VAR> __device__ __forceinline__ uint32_t lds_skew(uint32_t byte_off)
     {
-    if constexpr (VAR & VAR_GLDS)
+    if constexpr ((VAR & VAR_GLDS) || (VAR & VAR_LINEAR_LDS))
         return byte_off;
     else
         return byte_off + ((byte_off >> 7) << 4);
@@ -739,8 +740,10 @@ template<int MODE>
 static void launch_mode(bool waves, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
                         const PackArgs& args)
     {
-    switch (var & 7)
+    switch (var & 15)
         {
+        case 8: launch_one<MODE, 8>(waves, blocks, lds_bytes, stream, args); break;
+        case 12: launch_one<MODE, 12>(waves, blocks, lds_bytes, stream, args); break;
         case 0: launch_one<MODE, 0>(waves, blocks, lds_bytes, stream, args); break;
         case 1: launch_one<MODE, 1>(waves, blocks, lds_bytes, stream, args); break;
         case 2: launch_one<MODE, 2>(waves, blocks, lds_bytes, stream, args); break;
@@ -876,7 +879,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
             per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
         if (const char* e = getenv("PGSD_PACK_VARIANT"))
-            var = atoi(e) & 7;
+            var = atoi(e) & 15;
         if (const char* e = getenv("PGSD_PACK_TILE"))
             tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
         if (max_rowbytes * 16 > PACK_WAVE_LDS)
@@ -920,7 +923,8 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             for (uint32_t k = 0; k < args.n_groups; k++)
                 {
                 size_t lin = (size_t)tile * args.g[k].rowbytes;
-                size_t need = (lin + ((lin >> 7) << 4) + 31) & ~(size_t)15; // skewed image (lds_skew)
+                const bool skewed = !(var & (VAR_GLDS | VAR_LINEAR_LDS));
+                size_t need = ((skewed ? lin + ((lin >> 7) << 4) : lin) + 31) & ~(size_t)15; // see lds_skew
                 if (used != 0 && used + need > lds_budget)
                     {
                     args.batch_start[++args.n_batches] = (uint8_t)k;

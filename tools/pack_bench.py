@@ -109,7 +109,7 @@ def to_c(jobs):
     return arr
 
 
-def run(workload, N, iters, warmup, sleep_ms=0.0):
+def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
     gen = torch.Generator(device="cuda").manual_seed(1234)
     probe, algo, moved, _ = make_jobs(workload, 1024, gen)
     per_set = moved / 1024 * N
@@ -131,11 +131,19 @@ def run(workload, N, iters, warmup, sleep_ms=0.0):
         if sleep_ms > 0:
             torch.cuda.synchronize()
             time.sleep(sleep_ms * 1e-3)   # let the GPU idle between launches, like a snapshot every few ms
+        if variants:
+            os.environ["PGSD_PACK_VARIANT"] = variants[i % len(variants)]   # interleaved A/B in one process
         evs[i][0].record()
         _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
         evs[i][1].record()
     torch.cuda.synchronize()
     ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    if variants:
+        out = {"workload": workload, "N": N, "interleaved": True}
+        for k, v in enumerate(variants):
+            tv = ts[k::len(variants)]
+            out["var" + v] = {"median_us": round(float(np.median(tv)) * 1e6, 2), "min_us": round(float(tv.min()) * 1e6, 2)}
+        return out
     med, mn = float(np.median(ts)), float(ts.min())
     return {"workload": workload, "N": N, "sets": n_sets, "median_us": round(med * 1e6, 2), "min_us": round(mn * 1e6, 2),
             "algo_GBps": round(algo / med / 1e9, 1), "moved_GBps": round(moved / med / 1e9, 1),
@@ -149,8 +157,9 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sleep-ms", type=float, default=0.0)
+    ap.add_argument("--variants", default="", help="comma list of PGSD_PACK_VARIANT values to interleave")
     a = ap.parse_args()
     for w in a.workloads.split(","):
-        r = run(w, a.N, a.iters, a.warmup, a.sleep_ms)
+        r = run(w, a.N, a.iters, a.warmup, a.sleep_ms, [v for v in a.variants.split(',') if v] or None)
         r['sleep_ms'] = a.sleep_ms
         print(json.dumps(r), flush=True)
