@@ -935,8 +935,13 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                 lds_bytes = std::max(lds_bytes, used);
                 }
             args.batch_start[++args.n_batches] = (uint8_t)args.n_groups;
+            // never ask for more workgroups per CU than the 160 KiB of LDS admit: the surplus
+            // would queue behind the resident ones and run as a ragged second wave
+            uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
+            if (resident < 1)
+                resident = 1;
             uint64_t blocks = args.n_tiles;
-            uint64_t cap = (uint64_t)num_cus() * per_cu;
+            uint64_t cap = (uint64_t)num_cus() * std::min<uint64_t>(per_cu, resident);
             if (blocks > cap)
                 blocks = cap;
             launch_variant(false, mode, var, (unsigned)blocks, lds_bytes, stream, args);
