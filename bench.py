@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
     ap.add_argument("--separate-id", action="store_true", help="typeid from its own uint32 array instead of pos.w")
+    ap.add_argument("--schema", choices=["pvi", "sph"], default="pvi",
+                    help="pvi: position+velocity+typeid (headline); sph: the full PGSD-SPH particle schema, "
+                         "112 B/particle in 15 chunks (BASELINE config 4 workload)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -167,6 +170,29 @@ def main():
               ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
               ("particles/typeid", id_field)]
 
+    payload_bpp, algo_bpp = PAYLOAD_BYTES_PER_PARTICLE, ALGO_BYTES_PER_PARTICLE
+    if args.schema == "sph":
+        # hoomd.py:167-184: typeid, mass, body, position, velocity, slength, density, pressure, energy,
+        # auxiliary1-4, image -- from HOOMD-SPH-style device arrays (Scalar4 / int3-as-int4 / int)
+        dpe = torch.rand((N, 4), generator=g, device="cuda")                 # density, pressure, energy, slength
+        aux = [torch.randn((N, 4), generator=g, device="cuda") for _ in range(4)]
+        img = torch.randint(-2, 3, (N, 4), generator=g, device="cuda", dtype=torch.int32)
+        body = torch.full((N,), -1, device="cuda", dtype=torch.int32)
+        fields = [("particles/typeid", id_field),
+                  ("particles/mass", fl.DeviceField.from_tensor(vel, columns=(3, 4))),
+                  ("particles/body", fl.DeviceField.from_tensor(body)),
+                  ("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
+                  ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
+                  ("particles/slength", fl.DeviceField.from_tensor(dpe, columns=(3, 4))),
+                  ("particles/density", fl.DeviceField.from_tensor(dpe, columns=(0, 1))),
+                  ("particles/pressure", fl.DeviceField.from_tensor(dpe, columns=(1, 2))),
+                  ("particles/energy", fl.DeviceField.from_tensor(dpe, columns=(2, 3)))]
+        fields += [("particles/auxiliary%d" % (k + 1), fl.DeviceField.from_tensor(a, columns=(0, 3)))
+                   for k, a in enumerate(aux)]
+        fields.append(("particles/image", fl.DeviceField.from_tensor(img, columns=(0, 3))))
+        payload_bpp, algo_bpp = 112, 224
+        layout = "HOOMD-SPH device arrays (Scalar4 pos/vel/dpe/aux1-4, int4 image, int body), full SPH schema"
+
     path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
     f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
     f.configure_device(device=local_rank, slab_bytes=args.slab_mib << 20, n_slabs=args.slabs,
@@ -222,14 +248,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pack_traffic.json")) as tf:
             tj = json.load(tf)
-        if tj.get("particles") == N:
+        if tj.get("particles") == N and args.schema == "pvi" and not args.separate_id:
             traffic = tj["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
 
-    total_bytes = world * args.steps * N * PAYLOAD_BYTES_PER_PARTICLE
+    total_bytes = world * args.steps * N * payload_bpp
     value = total_bytes / dt / 1e9
-    achieved = ALGO_BYTES_PER_PARTICLE * N / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
+    achieved = algo_bpp * N / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     out = {
         "metric": "snapshot pack+write GB/s at 10M particles/GPU",
         "value": round(value, 3),
@@ -246,18 +272,18 @@ def main():
         "config": {"workload": "%d particles/GPU, position+velocity+typeid packed from %s, "
                                "%s allgather of row counts, one shared GSD file on %s"
                                % (N, layout, comm_backend, args.dir),
-                   "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * PAYLOAD_BYTES_PER_PARTICLE,
+                   "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "pack_tiles_kernel", "avg_ms": round(pack_ms, 5),
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PARTICLE * N},
+                     "algorithmic_bytes_per_launch": algo_bpp * N},
         "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
                            "note": "sum over ranks of the pack kernel rate (independent kernels, one per GPU)"},
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.schema == "pvi":
         out["cpu_baseline"] = cpu_baseline_reference(N, 12, args.dir) or cpu_baseline(N, 8, args.dir)
     print(json.dumps(out))
     if world > 1:
