@@ -220,6 +220,24 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stats = f.device_stats()
+
+    # What a simulation is blocked for per snapshot when it seals frames asynchronously: issue the
+    # frame, wait for the pack kernels only (the arrays may then change), let copy + write run on.
+    stall_ms = None
+    if world == 1:
+        stalls = []
+        for i in range(3):
+            f.frame_sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            counts, row0, n_global = pdist.partition_rows(N)
+            f.write_chunk("configuration/step", np.array([10 ** 6 + i], dtype=np.uint64), write_all=False)
+            f.write_chunks(fields, offset=counts, rank=rank)
+            f.end_frame(wait=False)
+            f.wait_packed()
+            stalls.append((time.perf_counter() - t1) * 1e3)
+        f.frame_sync()
+        stall_ms = round(min(stalls), 3)
     f.close()
 
     if world > 1:
@@ -280,6 +298,7 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bpp * N},
         "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
                            "note": "sum over ranks of the pack kernel rate (independent kernels, one per GPU)"},
+        "snapshot_stall_ms": stall_ms,
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }

@@ -323,6 +323,19 @@ extern "C"
                                  uint64_t N_global,
                                  uint64_t offset_rows);
 
+    /* Seal the frame like pgsd_end_frame, but do not wait for its device chunks: the frame
+       counter advances and names / small-chunk buffers / index entries are committed now, while
+       the device->host copies and the pwrite()s of the frame keep running behind the caller.
+       What a simulation waits for per snapshot is then only the pack kernels
+       (pgsd_device_wait_packed), not the file.  The frame's bytes are in the file after
+       pgsd_frame_sync(), or after the next pgsd_end_frame / pgsd_flush / pgsd_close /
+       pgsd_find_chunk / pgsd_read_chunk on this handle.  When the on-disk index has to be
+       relocated (every few hundred chunks) the call degrades to the synchronous pgsd_end_frame.
+       The file layout is identical either way.  Collective like pgsd_end_frame. */
+    int pgsd_end_frame_async(struct pgsd_handle* handle);
+    /* Wait until the device chunks of all asynchronously sealed frames of THIS rank are in the file. */
+    int pgsd_frame_sync(struct pgsd_handle* handle);
+
     /* Block until every pack kernel issued for the open frame has finished (the source
        arrays may be overwritten again); copies and file writes keep running. */
     int pgsd_device_wait_packed(struct pgsd_handle* handle);

@@ -123,6 +123,9 @@ class DevicePipeline
         if (failed())
             return PGSD_ERROR_DEVICE;
         HIP_TRY(hipSetDevice(m_cfg.device));
+        int rrc = recycle_staging();
+        if (rrc != PGSD_SUCCESS)
+            return rrc;
 
         std::vector<pgsd_pack_job> jobs;
         uint64_t bytes_in = 0, bytes_out = 0;
@@ -381,6 +384,42 @@ class DevicePipeline
         {
         std::lock_guard<std::mutex> g(m_mutex);
         return !m_error.empty();
+        }
+
+    // Staging is recycled when nothing is in flight (cheap, also serves asynchronously sealed
+    // frames that have drained on their own); if frames are produced faster than the file takes
+    // them, block once staging exceeds the soft cap instead of growing without bound.
+    int recycle_staging()
+        {
+        size_t used = 0;
+        for (auto& a : m_arenas)
+            used += a.used;
+        if (used == 0)
+            return PGSD_SUCCESS;
+        bool idle;
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            idle = m_outstanding == 0 && m_reads_outstanding == 0 && m_jobs.empty();
+            }
+        const size_t soft_cap = (size_t)6 << 30;
+        if (!idle && used < soft_cap)
+            return PGSD_SUCCESS;
+        if (!idle)
+            {
+            std::unique_lock<std::mutex> lk(m_mutex);
+            m_cv_done.wait(lk, [this] { return (m_outstanding == 0 && m_reads_outstanding == 0) || !m_error.empty(); });
+            }
+        hipError_t e = hipStreamSynchronize(m_copy_stream);
+        if (e != hipSuccess)
+            {
+            fail(std::string("stream synchronize: ") + hipGetErrorString(e));
+            return PGSD_ERROR_DEVICE;
+            }
+        collect_timings();
+        release_events();
+        for (auto& a : m_arenas)
+            a.used = 0;
+        return failed() ? PGSD_ERROR_DEVICE : PGSD_SUCCESS;
         }
 
     int arena_alloc(size_t bytes, void** out)

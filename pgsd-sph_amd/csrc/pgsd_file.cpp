@@ -161,6 +161,7 @@ struct Impl
     uint64_t maxbuf = DEFAULT_MAXIMUM_WRITE_BUFFER_SIZE;
     uint64_t idxbuf = DEFAULT_INDEX_ENTRIES_TO_BUFFER;
     bool dirty_data = false; // a direct/device chunk was written since the last flush
+    bool inflight = false;   // an asynchronous end_frame left device chunks on their way to the file
     WriterPool* pool = nullptr;
     DevicePipeline* dev = nullptr;
     pgsd_device_config devcfg;
@@ -576,23 +577,36 @@ static int expand_file_index(Impl* s, size_t size_required, int* local_rc)
     }
 
 // pgsd_flush, pgsd.c:1955-2070
-static int do_flush(Impl* s)
+static int do_flush(Impl* s, bool async = false)
     {
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
 
     // Replicated state tells every rank alike whether there is anything to do.
     bool work = s->frame_n_names > 0 || !s->buffer_index.empty() || !s->frame_index.empty()
-                || s->dirty_data;
+                || s->dirty_data || s->inflight;
     for (uint64_t b : s->wb_sizes)
         work = work || b > 0;
     if (!work)
         return PGSD_SUCCESS;
 
+    // Asynchronous sealing commits the metadata now and lets the device chunks finish in
+    // the background -- unless the on-disk index must move, which needs the file's true end
+    // and therefore every byte of every rank in place (decided alike on all ranks).
+    if (async && s->pending <= s->frame_index.size())
+        {
+        uint64_t will_write = s->frame_index.size() + s->buffer_index.size() - s->pending;
+        if (s->file_index_size + will_write > s->file_index.size())
+            async = false;
+        }
+
     int local_rc = PGSD_SUCCESS;
     // device chunks of this rank must be in the file before the frame is sealed
-    if (s->dev)
+    if (s->dev && async)
+        s->inflight = true;
+    else if (s->dev)
         {
+        s->inflight = false;
         std::string err;
         int drc = device_pipeline_drain(s->dev, &err);
         if (drc != PGSD_SUCCESS)
@@ -655,7 +669,7 @@ static int do_flush(Impl* s)
     return agree_status(s, local_rc);
     }
 
-static int do_end_frame(Impl* s)
+static int do_end_frame(Impl* s, bool async = false)
     {
     // pgsd.c:1916-1953
     if (s->flags == PGSD_OPEN_READONLY)
@@ -663,7 +677,7 @@ static int do_end_frame(Impl* s)
     s->cur_frame++;
     s->pending = 0;
     if (!s->frame_index.empty() || s->buffer_index.size() > s->idxbuf)
-        return do_flush(s);
+        return do_flush(s, async);
     return PGSD_SUCCESS;
     }
 
@@ -953,6 +967,31 @@ extern "C" int pgsd_end_frame(struct pgsd_handle* handle)
         return PGSD_ERROR_INVALID_ARGUMENT;
     int rc = do_end_frame(s);
     publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_end_frame_async(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = do_end_frame(s, true);
+    publish(handle, s);
+    return rc;
+    }
+
+extern "C" int pgsd_frame_sync(struct pgsd_handle* handle)
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!s->dev || !s->inflight)
+        return PGSD_SUCCESS;
+    std::string err;
+    int rc = device_pipeline_drain(s->dev, &err);
+    s->inflight = false;
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
     return rc;
     }
 

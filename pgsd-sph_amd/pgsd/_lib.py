@@ -141,6 +141,8 @@ _sig("pgsd_open", c_i32, HP, c_cp, c_i32)
 _sig("pgsd_close", c_i32, HP)
 _sig("pgsd_end_frame", c_i32, HP)
 _sig("pgsd_flush", c_i32, HP)
+_sig("pgsd_end_frame_async", c_i32, HP)
+_sig("pgsd_frame_sync", c_i32, HP)
 _sig("pgsd_write_chunk", c_i32, HP, c_cp, c_i32, c_u64, c_u32, c_u64, c_u32, c_u64, c_u64,
      ctypes.c_bool, c_u8, c_vp)
 _sig("pgsd_find_chunk", ctypes.POINTER(IndexEntry), HP, c_u64, c_cp)

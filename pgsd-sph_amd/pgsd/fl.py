@@ -245,6 +245,7 @@ class PGSDFile(object):
         self.__handle = _lib.Handle()
         self.__keepalive = []
         self.__explicit_stream = False
+        self.__async_keep = []
 
         if overwrite:
             if application is None:
@@ -294,12 +295,31 @@ class PGSDFile(object):
             self.__keepalive = []
             _raise_on_error(retval, self.__name)
 
-    def end_frame(self, write_all=True):
-        """Complete the current frame (fl.pyx:460-506); device chunks are in the file on return."""
+    def end_frame(self, write_all=True, wait=True):
+        """Complete the current frame (fl.pyx:460-506).
+
+        With ``wait=True`` (default, the reference's behaviour) the frame is in the file on
+        return.  ``wait=False`` seals the frame but lets its device chunks finish in the
+        background (``pgsd_end_frame_async``): call :meth:`wait_packed` before overwriting the
+        source arrays and :meth:`frame_sync` (or any later synchronous call) before relying on the
+        file contents.
+        """
         self._check_open()
         logger.debug('end frame: ' + self.__name)
-        retval = lib.pgsd_end_frame(self._h())
-        self.__keepalive = []
+        if wait:
+            retval = lib.pgsd_end_frame(self._h())
+            self.__keepalive = []
+        else:
+            retval = lib.pgsd_end_frame_async(self._h())
+            self.__async_keep.append(self.__keepalive)
+            self.__keepalive = []
+        _raise_on_error(retval, self.__name)
+
+    def frame_sync(self):
+        """Wait until every asynchronously sealed frame of this rank is in the file."""
+        self._check_open()
+        retval = lib.pgsd_frame_sync(self._h())
+        self.__async_keep = []
         _raise_on_error(retval, self.__name)
 
     def flush(self, write_all=True):

@@ -184,3 +184,48 @@ def test_pipeline_soak_random_frames(tmp_path):
     assert lib.oracle_close(h) == 0
     with open(mine, 'rb') as a, open(ref, 'rb') as b:
         assert a.read() == b.read()
+
+
+def test_async_end_frame_keeps_layout_and_snapshots_values(tmp_path):
+    """end_frame(wait=False): the simulation only waits for the pack kernels, the copies and file
+    writes run behind it.  The source arrays are overwritten in place right after wait_packed(), so
+    the file must hold the values as they were when each frame was packed; 60 frames x 3 chunks also
+    cross an on-disk index relocation, where the call degrades to the synchronous path.  The file
+    must equal the oracle's (same layout as with synchronous end_frame)."""
+    import pgsd.fl as fl
+    N = 40_000
+    rng = np.random.default_rng(77)
+    mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
+    lib = S.oracle_lib()
+    rc = ctypes.c_int(0)
+    h = lib.oracle_create_and_open(ref.encode(), 1, b'app', b'hoomd', lib.oracle_make_version(1, 4), 1, 0,
+                                   ctypes.byref(rc))
+    f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+    f.configure_device(slab_bytes=64 * 1024, n_slabs=4)
+    dpos = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    dvel = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    for frame in range(60):
+        pos4 = G.rand_array(rng, (N, 4), np.float32)
+        vel4 = G.rand_array(rng, (N, 4), np.float32)
+        dpos.copy_(torch.from_numpy(pos4), non_blocking=False)      # the "simulation" overwrites in place
+        dvel.copy_(torch.from_numpy(vel4), non_blocking=False)
+        step = np.array([frame], dtype=np.uint64)
+        f.write_chunk('configuration/step', step, write_all=False)
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
+                        ('particles/velocity', fl.DeviceField.from_tensor(dvel, columns=(0, 3)))],
+                       offset=np.array([N]))
+        f.end_frame(wait=False)
+        f.wait_packed()                                              # now the arrays may change again
+        for name, t, M, all_, arr in (('configuration/step', 4, 1, False, step.reshape(1, 1)),
+                                      ('particles/position', 9, 3, True, np.ascontiguousarray(pos4[:, :3])),
+                                      ('particles/velocity', 9, 3, True, np.ascontiguousarray(vel4[:, :3]))):
+            n = arr.shape[0]
+            assert S.oracle_write_chunk(lib, h, name, t, [arr], M, n, M, [0], [n * M], all_) == 0
+        assert lib.oracle_end_frame(h) == 0
+    f.frame_sync()
+    assert f.nframes == 60
+    np.testing.assert_array_equal(f.read_chunk(59, 'particles/velocity'), vel4[:, :3])
+    f.close()
+    assert lib.oracle_close(h) == 0
+    with open(mine, 'rb') as a, open(ref, 'rb') as b:
+        assert a.read() == b.read()
