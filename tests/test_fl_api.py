@@ -349,3 +349,18 @@ def test_partial_row_read(tmp_gsd):
         out = np.zeros((5, 3), dtype=np.float32)
         assert _lib.lib.pgsd_read_chunk(h, out.ctypes.data, e, 5, 3, 7, True) == 0
         np.testing.assert_array_equal(out, data[7:12])
+
+
+def test_async_end_frame_on_host_data_is_the_same_file(tmp_path):
+    """end_frame(wait=False) with host arrays only: nothing is in flight, the file equals the one
+    written with synchronous frames."""
+    a, b = str(tmp_path / "a.gsd"), str(tmp_path / "b.gsd")
+    for path, wait in ((a, True), (b, False)):
+        with create(path) as f:
+            for i in range(50):
+                f.write_chunk('x', np.arange(7, dtype=np.float32) + i)
+                f.write_chunk('s', np.array([i], dtype=np.uint64), write_all=False)
+                f.end_frame(wait=wait)
+            f.frame_sync()
+    with open(a, 'rb') as fa, open(b, 'rb') as fb:
+        assert fa.read() == fb.read()
