@@ -296,8 +296,12 @@ class HOOMDTrajectory(object):
         from ._lib import lib
         return lib.pgsd_comm_rank(), lib.pgsd_comm_size()
 
-    def append(self, frame):
+    def append(self, frame, wait=True):
         """Append a frame (collective over the ranks of the installed communicator).
+
+        ``wait=False`` seals the frame asynchronously (`pgsd.fl.PGSDFile.end_frame`): call
+        ``trajectory.file.wait_packed()`` before changing GPU-resident arrays of the frame and
+        ``trajectory.file.frame_sync()`` before relying on the file.
 
         Fields that are ``None`` are not written.  Host fields that equal the initial frame or
         the default value are elided exactly as upstream GSD does (hoomd.py:654-694); ranks
@@ -386,7 +390,7 @@ class HOOMDTrajectory(object):
         for log, data in frame.log.items():
             self.file.write_chunk('log/' + log, data, None, rank, False)
 
-        self.file.end_frame()
+        self.file.end_frame(wait=wait)
 
     def _flush_device_fields(self, device_fields, part_dist, rank):
         if device_fields:
