@@ -157,10 +157,10 @@ class DevicePipeline
             {
             HIP_TRY(hipEventCreate(&ev0));
             HIP_TRY(hipEventCreate(&ev1));
-            HIP_TRY(hipEventRecord(ev0, m_pack_stream));
             }
         std::string err;
-        int rc = launch_pack((uint32_t)jobs.size(), jobs.data(), N, m_pack_stream, &err);
+        // profiled: the events are stamped by the kernel dispatch itself (begin / end)
+        int rc = launch_pack((uint32_t)jobs.size(), jobs.data(), N, m_pack_stream, &err, ev0, ev1);
         if (rc != PGSD_SUCCESS)
             {
             fail(err);
@@ -168,7 +168,6 @@ class DevicePipeline
             }
         if (m_cfg.profile)
             {
-            HIP_TRY(hipEventRecord(ev1, m_pack_stream));
             std::lock_guard<std::mutex> g(m_mutex);
             m_pack_events.push_back({ev0, ev1});
             }

@@ -28,6 +28,7 @@
 #include "pgsd_pack.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -727,47 +728,63 @@ static int num_cus()
     }
 
 template<int MODE, int VAR>
-static void launch_one(bool waves, unsigned blocks, size_t lds_bytes, hipStream_t stream, const PackArgs& args)
+static void launch_one(bool waves, unsigned blocks, size_t lds_bytes, hipStream_t stream, const PackArgs& args,
+                       hipEvent_t ev_start, hipEvent_t ev_stop)
     {
+    // hipExtLaunchKernelGGL stamps the events with the dispatch's own begin / end times, so a
+    // profiled launch measures the kernel and nothing else (what rocprofv3 reports)
     if (waves)
-        hipLaunchKernelGGL((pack_waves_kernel<MODE, VAR & ~VAR_GLDS>), dim3(blocks), dim3(PACK_THREADS), lds_bytes,
-                           stream, args);
+        hipExtLaunchKernelGGL((pack_waves_kernel<MODE, VAR & ~VAR_GLDS>), dim3(blocks), dim3(PACK_THREADS),
+                              (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
     else
-        hipLaunchKernelGGL((pack_tiles_kernel<MODE, VAR>), dim3(blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+        hipExtLaunchKernelGGL((pack_tiles_kernel<MODE, VAR>), dim3(blocks), dim3(PACK_THREADS), (uint32_t)lds_bytes,
+                              stream, ev_start, ev_stop, 0, args);
     }
 
 template<int MODE>
 static void launch_mode(bool waves, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
-                        const PackArgs& args)
+                        const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
     {
     switch (var & 15)
         {
-        case 8: launch_one<MODE, 8>(waves, blocks, lds_bytes, stream, args); break;
-        case 12: launch_one<MODE, 12>(waves, blocks, lds_bytes, stream, args); break;
-        case 0: launch_one<MODE, 0>(waves, blocks, lds_bytes, stream, args); break;
-        case 1: launch_one<MODE, 1>(waves, blocks, lds_bytes, stream, args); break;
-        case 2: launch_one<MODE, 2>(waves, blocks, lds_bytes, stream, args); break;
-        case 3: launch_one<MODE, 3>(waves, blocks, lds_bytes, stream, args); break;
-        case 4: launch_one<MODE, 4>(waves, blocks, lds_bytes, stream, args); break;
-        case 5: launch_one<MODE, 5>(waves, blocks, lds_bytes, stream, args); break;
-        case 6: launch_one<MODE, 6>(waves, blocks, lds_bytes, stream, args); break;
-        default: launch_one<MODE, 7>(waves, blocks, lds_bytes, stream, args); break;
+        case 8: launch_one<MODE, 8>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 12: launch_one<MODE, 12>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 0: launch_one<MODE, 0>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 1: launch_one<MODE, 1>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 2: launch_one<MODE, 2>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 3: launch_one<MODE, 3>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 4: launch_one<MODE, 4>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 5: launch_one<MODE, 5>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        case 6: launch_one<MODE, 6>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
+        default: launch_one<MODE, 7>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
         }
     }
 
 static void launch_variant(bool waves, int mode, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
-                           const PackArgs& args)
+                           const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
     {
     if (mode == PACK_MODE_W32)
-        launch_mode<PACK_MODE_W32>(waves, var, blocks, lds_bytes, stream, args);
+        launch_mode<PACK_MODE_W32>(waves, var, blocks, lds_bytes, stream, args, ev_start, ev_stop);
     else if (mode == PACK_MODE_F64_F32)
-        launch_mode<PACK_MODE_F64_F32>(waves, var, blocks, lds_bytes, stream, args);
+        launch_mode<PACK_MODE_F64_F32>(waves, var, blocks, lds_bytes, stream, args, ev_start, ev_stop);
     else
-        launch_mode<PACK_MODE_GENERIC>(waves, (var & VAR_GLDS), blocks, lds_bytes, stream, args);
+        launch_mode<PACK_MODE_GENERIC>(waves, (var & VAR_GLDS), blocks, lds_bytes, stream, args, ev_start, ev_stop);
     }
 
-int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
+struct PendingLaunch
     {
+    bool waves;
+    int mode, var;
+    unsigned blocks;
+    size_t lds_bytes;
+    PackArgs args;
+    };
+
+int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err,
+                hipEvent_t ev_start, hipEvent_t ev_stop)
+    {
+    std::vector<PendingLaunch> pending;
+    bool generic_used = false;
     if (n_jobs == 0 || N == 0)
         return PGSD_SUCCESS;
     for (uint32_t i = 0; i < n_jobs; i++)
@@ -805,6 +822,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t cap = (uint64_t)num_cus() * 8;
             if (blocks > cap)
                 blocks = cap;
+            if (!generic_used && ev_start)
+                (void)hipEventRecord(ev_start, stream); // mixed launches: bracket them all
+            generic_used = true;
             hipLaunchKernelGGL(pack_generic_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), 0, stream, a);
             done[i] = true;
             }
@@ -901,7 +921,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t max_blocks = (N + 255) / 256;
             if (blocks > max_blocks)
                 blocks = max_blocks;
-            launch_variant(true, mode, var, (unsigned)blocks, (PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, stream, args);
+            pending.push_back({true, mode, var, (unsigned)blocks, (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, args});
             }
         else
             {
@@ -944,12 +964,25 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t cap = (uint64_t)num_cus() * std::min<uint64_t>(per_cu, resident);
             if (blocks > cap)
                 blocks = cap;
-            launch_variant(false, mode, var, (unsigned)blocks, lds_bytes, stream, args);
+            pending.push_back({false, mode, var, (unsigned)blocks, lds_bytes, args});
             }
         while (next < n_jobs && done[next])
             next++;
         if (next == n_jobs)
             break;
+        }
+    for (size_t i = 0; i < pending.size(); i++)
+        {
+        const PendingLaunch& L = pending[i];
+        hipEvent_t s0 = (!generic_used && i == 0) ? ev_start : nullptr;
+        hipEvent_t s1 = (!generic_used && i + 1 == pending.size()) ? ev_stop : nullptr;
+        launch_variant(L.waves, L.mode, L.var, L.blocks, L.lds_bytes, stream, L.args, s0, s1);
+        }
+    if (ev_stop && (generic_used || pending.empty()))
+        {
+        if (!generic_used && ev_start)
+            (void)hipEventRecord(ev_start, stream);
+        (void)hipEventRecord(ev_stop, stream);
         }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -116,7 +116,9 @@ struct UnpackArgs
 int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
 
 // Enqueue the pack of `n_jobs` fields of N rows each on `stream`. Returns a pgsd_error.
-int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
+// ev_start / ev_stop (optional) receive the begin time of the first and the end time of the last kernel.
+int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err,
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // algorithmic traffic of one job: bytes that must be read (needed columns only, plus the
 // gather index) and chunk bytes written
