@@ -39,8 +39,23 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef PGSD_DRIVER_REF
+#if defined(PGSD_DRIVER_REF) || defined(PGSD_DRIVER_MPI)
 #include <mpi.h>
+#endif
+
+#ifdef PGSD_DRIVER_MPI
+/* third build: the PRODUCT under the reference's own launcher (mpiexec); the library's
+   collectives are forwarded to MPI through the communicator vtable */
+static int mpi_allgather_cb(void* ctx, const void* send, void* recv, size_t bytes)
+    {
+    (void)ctx;
+    return MPI_Allgather((void*)send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, MPI_COMM_WORLD) != MPI_SUCCESS;
+    }
+static int mpi_barrier_cb(void* ctx)
+    {
+    (void)ctx;
+    return MPI_Barrier(MPI_COMM_WORLD) != MPI_SUCCESS;
+    }
 #endif
 
 static int g_rank = 0, g_size = 1;
@@ -157,6 +172,20 @@ int main(int argc, char** argv)
     MPI_Init(NULL, NULL);
     MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
     MPI_Comm_size(MPI_COMM_WORLD, &g_size);
+#elif defined(PGSD_DRIVER_MPI)
+    MPI_Init(NULL, NULL);
+    MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &g_size);
+    {
+    struct pgsd_comm c;
+    memset(&c, 0, sizeof(c));
+    c.rank = g_rank;
+    c.size = g_size;
+    c.allgather = mpi_allgather_cb;
+    c.barrier = mpi_barrier_cb;
+    if (pgsd_comm_set_default(&c) != PGSD_SUCCESS)
+        return 3;
+    }
 #else
     if (pgsd_comm_init_from_env() != PGSD_SUCCESS)
         {
@@ -320,6 +349,9 @@ int main(int argc, char** argv)
         }
     fclose(f);
 #ifdef PGSD_DRIVER_REF
+    MPI_Finalize();
+#elif defined(PGSD_DRIVER_MPI)
+    pgsd_comm_finalize();
     MPI_Finalize();
 #else
     pgsd_comm_finalize();

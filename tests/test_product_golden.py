@@ -18,3 +18,35 @@ def test_product_matches_reference_file(name, P, tmp_gsd):
     assert len(mine) == len(ref)
     assert mine == ref
     assert log == S.read_log(golden[:-4] + ".log")
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+MPI_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_mpi")
+
+
+@pytest.fixture(scope="module")
+def mpi_driver():
+    import subprocess
+    if not (os.path.exists(MPIEXEC) and os.path.exists("/opt/conda/include/mpi.h")):
+        pytest.skip("no MPI installation in this image")
+    product.build()
+    r = subprocess.run(["make", "-C", product.CSRC, "mpi"], capture_output=True)
+    if r.returncode != 0:
+        pytest.skip("cannot link against MPI: " + r.stderr.decode()[-300:])
+    return MPI_DRIVER
+
+
+@pytest.mark.parametrize("name,P", [("posvelid", 8), ("sph_full", 4), ("index_expand", 2), ("names_reloc", 5),
+                                    ("maxbuf", 4), ("reopen", 2), ("benchlike", 8)])
+def test_product_under_mpiexec_matches_reference_file(mpi_driver, name, P, tmp_gsd):
+    """Drop-in under the reference's own launcher: the driver source + libpgsd_amd.so, started with
+    `mpiexec -n P`, the library's collectives forwarded to MPI through the communicator vtable
+    (INTEGRATION.md section 1)."""
+    import subprocess
+    out = subprocess.run([MPIEXEC, "-n", str(P), mpi_driver, S.scenario_path(name), tmp_gsd],
+                         capture_output=True, timeout=180)
+    assert out.returncode == 0, out.stderr.decode()[-500:]
+    golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        assert f.read() == g.read()
+    assert [ln for ln in out.stdout.decode().splitlines() if ln.strip()] == S.read_log(golden[:-4] + ".log")
