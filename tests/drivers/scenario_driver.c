@@ -1,6 +1,6 @@
 /* scenario_driver.c -- replay a chunk-write scenario through the pgsd C ABI.
  *
- * Test infrastructure.  ONE source, TWO builds:
+ * Test infrastructure.  ONE source, THREE builds:
  *
  *   -DPGSD_DRIVER_REF   links the reference's own pgsd.c (compiled in place from
  *                       /root/reference by oracle/Makefile, output in oracle/_ref/)
@@ -10,7 +10,11 @@
  *                       rank/size from the shared-memory communicator
  *                       (PGSD_RANK / PGSD_NRANKS / PGSD_SHM_NAME), one process per rank.
  *
- * Both builds make exactly the same pgsd_* calls (the drop-in boundary of
+ *   -DPGSD_DRIVER_MPI   links libpgsd_amd.so AND MPI: the product under the reference's own
+ *                       launcher (mpiexec), its collectives forwarded to MPI_Allgather through
+ *                       the communicator vtable.
+ *
+ * All builds make exactly the same pgsd_* calls (the drop-in boundary of
  * /root/reference/pgsd/pgsd/pgsd.h:362-735), so `cmp` of the two output files is the
  * parity check of the host file layer.
  *
