@@ -255,6 +255,9 @@ def main():
         except OSError:
             pass
 
+    if world > 1:
+        dist.barrier()
+        pdist.finalize()          # tears down the library's RCCL communicator on every rank
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
