@@ -412,8 +412,10 @@ extern "C"
     /* Device twin of pgsd_read_chunk (reference pgsd.h:604-610) for a row slab: rows
        [row_offset, row_offset + N) of `chunk` (found with pgsd_find_chunk, valid on every rank)
        are read with pread, streamed to HBM through the pinned slab ring and unpacked by a HIP
-       kernel.  Asynchronous: complete after pgsd_device_wait_read(). Every rank reads its own
-       partition; no collective is involved. */
+       kernel.  Asynchronous: complete after pgsd_device_wait_read(), which also issues the
+       unpack of everything read since the last wait as one launch (chunks that together restore
+       whole rows of one array -- position.xyz + type id -- are written as whole rows). Every
+       rank reads its own partition; no collective is involved. */
     int pgsd_read_chunk_device(struct pgsd_handle* handle,
                                const struct pgsd_index_entry* chunk,
                                uint64_t N,

@@ -261,6 +261,7 @@ class DevicePipeline
             m_cv_done.wait(lk, [this] { return m_reads_outstanding == 0; });
             }
         (void)hipSetDevice(m_cfg.device);
+        launch_pending_unpacks();
         hipError_t e = hipStreamSynchronize(m_copy_stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(m_pack_stream);
@@ -576,6 +577,41 @@ class DevicePipeline
         m_cv_done.notify_all();
         }
 
+    // all chunks whose H2D copies are enqueued: one unpack launch per distinct row count, behind
+    // the copies
+    void launch_pending_unpacks()
+        {
+        std::vector<std::shared_ptr<ReadReq>> pending;
+            {
+            std::lock_guard<std::mutex> g(m_copy_mutex);
+            pending.swap(m_unpack_pending);
+            }
+        while (!pending.empty() && !failed())
+            {
+            const uint64_t N = pending.front()->N;
+            std::vector<pgsd_unpack_job> jobs;
+            std::vector<std::shared_ptr<ReadReq>> rest;
+            hipError_t e = hipSuccess;
+            for (auto& r : pending)
+                {
+                if (r->N != N)
+                    {
+                    rest.push_back(r);
+                    continue;
+                    }
+                jobs.push_back(r->job);
+                if (e == hipSuccess)
+                    e = hipStreamWaitEvent(m_pack_stream, r->all_copied, 0);
+                }
+            std::string err;
+            if (e != hipSuccess)
+                fail(std::string("read pipeline event: ") + hipGetErrorString(e));
+            else if (launch_unpack((uint32_t)jobs.size(), jobs.data(), N, m_pack_stream, &err) != PGSD_SUCCESS)
+                fail(err);
+            pending.swap(rest);
+            }
+        }
+
     void read_piece(std::shared_ptr<ReadReq> req, char* dst, size_t n, long long foff)
         {
         (void)hipSetDevice(m_cfg.device);
@@ -619,15 +655,14 @@ class DevicePipeline
             last = (--req->pieces_left == 0);
             if (last && !failed())
                 {
-                // every piece of this chunk has been enqueued on the copy stream before this point
+                // Every piece of this chunk has been enqueued on the copy stream before this point.
+                // The unpack itself is deferred to wait_read(): the chunks of a frame then go through
+                // ONE launch in which chunks restoring the same array are assembled into whole rows.
                 hipError_t e = hipEventRecord(req->all_copied, m_copy_stream);
-                if (e == hipSuccess)
-                    e = hipStreamWaitEvent(m_pack_stream, req->all_copied, 0);
-                std::string err;
                 if (e != hipSuccess)
                     fail(std::string("read pipeline event: ") + hipGetErrorString(e));
-                else if (launch_unpack(1, &req->job, req->N, m_pack_stream, &err) != PGSD_SUCCESS)
-                    fail(err);
+                else
+                    m_unpack_pending.push_back(req);
                 }
             }
         if (si >= 0)
@@ -695,6 +730,7 @@ class DevicePipeline
     WriterPool* m_read_pool = nullptr;
     std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
     size_t m_reads_outstanding = 0;
+    std::vector<std::shared_ptr<ReadReq>> m_unpack_pending; // guarded by m_copy_mutex
     std::thread m_dispatcher;
     std::mutex m_mutex;
     std::condition_variable m_cv_jobs, m_cv_slabs, m_cv_done;

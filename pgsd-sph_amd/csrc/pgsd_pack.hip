@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace pgsd_amd
     {
@@ -484,74 +485,190 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_generic_kernel(const PackGe
     }
 
 // ------------------------------------------------------------------ unpack (read path)
-// Inverse of the pack: a dense chunk tile (contiguous bytes) is streamed into LDS with
-// 16-byte loads; lane e then converts element e of the tile and stores it to its (row, column)
-// of the destination array.  Neighbouring lanes write neighbouring columns / rows, so a wave
-// store covers a dense span of the destination even when only 3 of 4 columns are written.
-template<int SSZ, int DSZ>
+// Inverse of the pack.  The dense tiles of ALL chunks of a launch (contiguous bytes) are
+// streamed into LDS with 16-byte non-temporal loads, one barrier, then
+//   * destination arrays whose rows are completely restored by this launch (position.xyz and
+//     the type id into a Scalar4 array, velocity.xyz and mass, double4 builds ...) are
+//     assembled row-wise in registers and written with 16-byte non-temporal stores: whole
+//     lines, no partial-line writes;
+//   * every other chunk is scattered element-wise: lane e converts element e of the tile and
+//     stores it to its (row, column); columns no chunk restores are left untouched.
+// W32 = every chunk and destination element is 4 bytes wide and moved unchanged.
+template<bool W32> __device__ __forceinline__ uint64_t unpack_elem(const char* p, uint32_t ssz, uint32_t dsz, uint32_t kind)
+    {
+    if constexpr (W32)
+        return *(const uint32_t*)p;
+    else
+        {
+        switch (ssz)
+            {
+            case 1: return dsz == 8 ? convert_elem<1, 8>(lds_load<1>(p), kind) : convert_elem<1, 4>(lds_load<1>(p), kind);
+            case 2: return dsz == 8 ? convert_elem<2, 8>(lds_load<2>(p), kind) : convert_elem<2, 4>(lds_load<2>(p), kind);
+            case 4: return dsz == 8 ? convert_elem<4, 8>(lds_load<4>(p), kind) : convert_elem<4, 4>(lds_load<4>(p), kind);
+            default: return dsz == 4 ? convert_elem<8, 4>(lds_load<8>(p), kind) : convert_elem<8, 8>(lds_load<8>(p), kind);
+            }
+        }
+    }
+
+template<bool W32>
 __device__ __forceinline__ void scatter_tile(const UnpackJob& j, const char* lds, uint32_t rows, uint64_t row0)
     {
-    const uint32_t M = j.M;
+    const uint32_t M = j.M, ssz = W32 ? 4u : j.ssz, dsz = W32 ? 4u : j.dsz;
     const uint32_t nelem = rows * M;
     for (uint32_t e = threadIdx.x; e < nelem; e += PACK_THREADS)
         {
         uint32_t row = (M == 1) ? e : __umulhi(e, j.magic);
         uint32_t col = e - row * M;
-        uint64_t raw = lds_load<SSZ>(lds + (size_t)e * SSZ);
-        uint64_t val = convert_elem<SSZ, DSZ>(raw, j.kind);
+        uint64_t val = unpack_elem<W32>(lds + (size_t)e * ssz, ssz, dsz, j.kind);
         uint64_t drow = j.order ? (uint64_t)j.order[row0 + row] : row0 + row;
-        char* p = (char*)j.dst + (drow * j.dst_stride + j.dst_col0 + col) * DSZ;
-        if constexpr (DSZ == 8)
+        char* p = (char*)j.dst + (drow * j.dst_stride + j.dst_col0 + col) * dsz;
+        if (dsz == 8)
             *(uint64_t*)p = val;
-        else if constexpr (DSZ == 4)
+        else if (dsz == 4)
             *(uint32_t*)p = (uint32_t)val;
-        else if constexpr (DSZ == 2)
+        else if (dsz == 2)
             *(uint16_t*)p = (uint16_t)val;
         else
             *(uint8_t*)p = (uint8_t)val;
         }
     }
 
-template<int SSZ> __device__ __forceinline__ void scatter_dispatch(const UnpackJob& j, const char* lds, uint32_t rows, uint64_t row0)
+// Where one column of an assembled destination row comes from (kept in LDS: lanes that build
+// different vectors of a wide row look up different columns).
+struct UnpackCol
     {
-    switch (j.dsz)
+    uint32_t base; // LDS byte offset of column 0 .. of row 0 of the chunk tile
+    uint32_t step; // bytes per chunk row
+    uint32_t ssz, kind;
+    };
+#define UNPACK_TABLE_BYTES (UNPACK_MAX_GROUPS * UNPACK_MAX_ROW_COLS * 16)
+
+// one 16-byte vector of a destination row per lane per step; rows are 16, 32 or 64 bytes
+template<bool W32>
+__device__ __forceinline__ void assemble_rows(const UnpackGroup& g, const UnpackCol* tab, const char* lds, uint32_t rows,
+                                              uint64_t row0)
+    {
+    const uint32_t shift = g.vec_shift, mask = (1u << shift) - 1u;
+    const uint32_t dsz = W32 ? 4u : g.dsz;
+    const uint32_t ept = 16u / dsz; // 4 or 2 elements per vector
+    const uint32_t nvec = rows << shift;
+    const uint32_t rowbytes = g.stride * dsz;
+    const uint32_t* order = g.order;
+    char* dst = (char*)g.dst;
+    if (shift == 0)
         {
-        case 1: scatter_tile<SSZ, 1>(j, lds, rows, row0); break;
-        case 2: scatter_tile<SSZ, 2>(j, lds, rows, row0); break;
-        case 4: scatter_tile<SSZ, 4>(j, lds, rows, row0); break;
-        default: scatter_tile<SSZ, 8>(j, lds, rows, row0); break;
+        // 16-byte rows (Scalar4 of floats / ints): the four column descriptors are loop invariants
+        UnpackCol d[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            d[k] = tab[k < ept ? k : 0];
+        for (uint32_t row = threadIdx.x; row < rows; row += PACK_THREADS)
+            {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++)
+                {
+                if (k >= ept)
+                    break;
+                uint64_t val = unpack_elem<W32>(lds + d[k].base + row * d[k].step, d[k].ssz, dsz, d[k].kind);
+                if (dsz == 8)
+                    {
+                    w[2 * k] = (uint32_t)val;
+                    w[2 * k + 1] = (uint32_t)(val >> 32);
+                    }
+                else
+                    w[k] = (uint32_t)val;
+                }
+            const uint64_t drow = order ? (uint64_t)order[row0 + row] : row0 + row;
+            u32x4 out = {w[0], w[1], w[2], w[3]};
+            __builtin_nontemporal_store(out, (u32x4*)(dst + drow * 16));
+            }
+        return;
+        }
+    for (uint32_t v = threadIdx.x; v < nvec; v += PACK_THREADS)
+        {
+        const uint32_t row = v >> shift, q = v & mask;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            {
+            if (k >= ept)
+                break;
+            const UnpackCol d = tab[q * ept + k];
+            uint64_t val = unpack_elem<W32>(lds + d.base + row * d.step, d.ssz, dsz, d.kind);
+            if (dsz == 8)
+                {
+                w[2 * k] = (uint32_t)val;
+                w[2 * k + 1] = (uint32_t)(val >> 32);
+                }
+            else
+                w[k] = (uint32_t)val;
+            }
+        const uint64_t drow = order ? (uint64_t)order[row0 + row] : row0 + row;
+        u32x4 out = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(out, (u32x4*)(dst + drow * rowbytes + (size_t)q * 16));
         }
     }
 
-__global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_kernel(const UnpackArgs args)
+template<bool W32> __global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_kernel(const UnpackArgs args)
     {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t TILE = args.tile_rows;
+    // column table of the assembled arrays, once per workgroup (chunk tiles start behind it)
+    UnpackCol* tab = (UnpackCol*)lds;
+    if (tid < args.n_groups * UNPACK_MAX_ROW_COLS)
+        {
+        const UnpackGroup& g = args.g[tid / UNPACK_MAX_ROW_COLS];
+        const uint32_t col = tid % UNPACK_MAX_ROW_COLS;
+        UnpackCol d = {0, 0, 4, 0};
+        if (col < g.stride)
+            {
+            const UnpackJob& j = args.j[g.col_job[col]];
+            d.base = j.lds_off + g.col_off[col] * j.ssz;
+            d.step = j.rowbytes;
+            d.ssz = j.ssz;
+            d.kind = j.kind;
+            }
+        tab[tid] = d;
+        }
+    // (the first tile's barrier publishes the table)
     for (uint64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x)
         {
         const uint64_t row0 = tile * TILE;
         const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+        // every chunk tile in flight before the first byte is consumed
         for (uint32_t ji = 0; ji < args.n_jobs; ji++)
             {
             const UnpackJob& j = args.j[ji];
             const char* gsrc = (const char*)j.src + row0 * j.rowbytes;
+            char* l = lds + j.lds_off;
             const uint32_t nbytes = rows * j.rowbytes;
             const uint32_t nvec = nbytes >> 4;
-            for (uint32_t v = tid; v < nvec; v += PACK_THREADS)
-                ((u32x4*)lds)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-            for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
-                lds[b] = gsrc[b];
-            __syncthreads();
-            switch (j.ssz)
+            uint32_t v = tid;
+            for (; v + 3 * PACK_THREADS < nvec; v += 4 * PACK_THREADS)
                 {
-                case 1: scatter_dispatch<1>(j, lds, rows, row0); break;
-                case 2: scatter_dispatch<2>(j, lds, rows, row0); break;
-                case 4: scatter_dispatch<4>(j, lds, rows, row0); break;
-                default: scatter_dispatch<8>(j, lds, rows, row0); break;
+                u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+                u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + PACK_THREADS);
+                u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * PACK_THREADS);
+                u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * PACK_THREADS);
+                ((u32x4*)l)[v] = a;
+                ((u32x4*)l)[v + PACK_THREADS] = b;
+                ((u32x4*)l)[v + 2 * PACK_THREADS] = c;
+                ((u32x4*)l)[v + 3 * PACK_THREADS] = d;
                 }
-            __syncthreads();
+            for (; v < nvec; v += PACK_THREADS)
+                ((u32x4*)l)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
+            for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
+                l[b] = gsrc[b];
             }
+        __syncthreads();
+        for (uint32_t gi = 0; gi < args.n_groups; gi++)
+            assemble_rows<W32>(args.g[gi], tab + gi * UNPACK_MAX_ROW_COLS, lds, rows, row0);
+        for (uint32_t ji = 0; ji < args.n_jobs; ji++)
+            if (!args.j[ji].in_group)
+                scatter_tile<W32>(args.j[ji], lds + args.j[ji].lds_off, rows, row0);
+        __syncthreads();
         }
     }
 
@@ -993,60 +1110,155 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         }
     return PGSD_SUCCESS;
     }
+// One batch of <= UNPACK_MAX_JOBS validated chunks -> one launch.
+static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, hipStream_t stream)
+    {
+    UnpackArgs args;
+    memset(&args, 0, sizeof(args));
+    args.N = N;
+    args.n_jobs = (uint32_t)jobs.size();
+    uint32_t sum_rowbytes = 0;
+    bool w32 = true;
+    for (uint32_t i = 0; i < args.n_jobs; i++)
+        {
+        args.j[i] = jobs[i];
+        sum_rowbytes += jobs[i].rowbytes;
+        w32 = w32 && jobs[i].ssz == 4 && jobs[i].dsz == 4 && jobs[i].kind == PACK_BITS;
+        }
+    // destination arrays whose rows this batch restores completely: dst row of 16, 32 or 64 bytes,
+    // 4- or 8-byte elements, every column written by exactly one chunk
+    for (uint32_t i = 0; i < args.n_jobs && args.n_groups < UNPACK_MAX_GROUPS; i++)
+        {
+        UnpackJob& a = args.j[i];
+        if (a.in_group)
+            continue;
+        const uint32_t rowbytes = a.dst_stride * a.dsz;
+        if ((a.dsz != 4 && a.dsz != 8) || (rowbytes != 16 && rowbytes != 32 && rowbytes != 64)
+            || (((uintptr_t)a.dst) & 15) != 0)
+            continue;
+        UnpackGroup g;
+        memset(&g, 0, sizeof(g));
+        uint8_t covered[UNPACK_MAX_ROW_COLS] = {0};
+        uint32_t n_cov = 0;
+        bool clean = true;
+        for (uint32_t k = i; k < args.n_jobs; k++)
+            {
+            const UnpackJob& b = args.j[k];
+            if (b.dst != a.dst || b.in_group)
+                continue;
+            if (b.order != a.order || b.dst_stride != a.dst_stride || b.dsz != a.dsz)
+                {
+                clean = false; // same array seen through different shapes: leave it to the element path
+                break;
+                }
+            for (uint32_t c = 0; c < b.M; c++)
+                {
+                if (covered[b.dst_col0 + c])
+                    clean = false;
+                covered[b.dst_col0 + c] = 1;
+                g.col_job[b.dst_col0 + c] = (uint8_t)k;
+                g.col_off[b.dst_col0 + c] = (uint8_t)c;
+                n_cov++;
+                }
+            }
+        if (!clean || n_cov != a.dst_stride)
+            continue;
+        g.dst = a.dst;
+        g.order = a.order;
+        g.stride = a.dst_stride;
+        g.dsz = a.dsz;
+        g.vec_shift = rowbytes == 16 ? 0u : (rowbytes == 32 ? 1u : 2u);
+        for (uint32_t k = i; k < args.n_jobs; k++)
+            if (args.j[k].dst == a.dst)
+                args.j[k].in_group = 1;
+        args.g[args.n_groups++] = g;
+        }
+    uint32_t tile = 16;
+    while (tile * 2 <= 1024 && (uint64_t)tile * 2 * sum_rowbytes <= UNPACK_LDS_BYTES)
+        tile <<= 1;
+    args.tile_rows = tile;
+    args.n_tiles = (N + tile - 1) / tile;
+    size_t lds_bytes = UNPACK_TABLE_BYTES; // the column table of the kernel sits in front
+    for (uint32_t i = 0; i < args.n_jobs; i++)
+        {
+        args.j[i].lds_off = (uint32_t)lds_bytes;
+        lds_bytes += (size_t)tile * args.j[i].rowbytes; // tile is a multiple of 16: stays 16-byte aligned
+        }
+    uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
+    uint64_t blocks = args.n_tiles;
+    uint64_t cap = (uint64_t)num_cus() * std::max<uint64_t>(1, std::min<uint64_t>(4, resident));
+    if (blocks > cap)
+        blocks = cap;
+    if (w32)
+        hipLaunchKernelGGL(unpack_tiles_kernel<true>, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+    else
+        hipLaunchKernelGGL(unpack_tiles_kernel<false>, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+    }
+
 int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
     {
     if (n_jobs == 0 || N == 0)
         return PGSD_SUCCESS;
-    for (uint32_t first = 0; first < n_jobs; first += UNPACK_MAX_JOBS)
+    std::vector<UnpackJob> all;
+    all.reserve(n_jobs);
+    for (uint32_t i = 0; i < n_jobs; i++)
         {
-        UnpackArgs args;
-        memset(&args, 0, sizeof(args));
-        args.N = N;
-        uint32_t max_rowbytes = 0;
-        for (uint32_t i = first; i < n_jobs && i < first + UNPACK_MAX_JOBS; i++)
+        const pgsd_unpack_job& q = jobs[i];
+        const uint32_t ssz = (uint32_t)sizeof_type(q.src_type), dsz = (uint32_t)sizeof_type(q.dst.dst_type);
+        const bool s_int = q.src_type <= PGSD_TYPE_INT64, d_int = q.dst.dst_type <= PGSD_TYPE_INT64;
+        bool ok = q.src && q.dst.dst && ssz && dsz && q.M && q.M <= PACK_MAX_M
+                  && q.dst.dst_col0 + q.M <= q.dst.dst_stride && (((uintptr_t)q.src) & 15) == 0
+                  && (((uintptr_t)q.dst.dst) & (dsz - 1)) == 0 && (uint64_t)q.M * ssz <= PACK_MAX_ROWBYTES;
+        if (q.dst.bitcast)
+            ok = ok && ssz == dsz;
+        else
+            ok = ok && !(!s_int && d_int) && !(s_int && !d_int && ssz == 8);
+        if (!ok)
             {
-            const pgsd_unpack_job& q = jobs[i];
-            const uint32_t ssz = (uint32_t)sizeof_type(q.src_type), dsz = (uint32_t)sizeof_type(q.dst.dst_type);
-            const bool s_int = q.src_type <= PGSD_TYPE_INT64, d_int = q.dst.dst_type <= PGSD_TYPE_INT64;
-            bool ok = q.src && q.dst.dst && ssz && dsz && q.M && q.M <= PACK_MAX_M
-                      && q.dst.dst_col0 + q.M <= q.dst.dst_stride && (((uintptr_t)q.src) & 15) == 0
-                      && (((uintptr_t)q.dst.dst) & (dsz - 1)) == 0 && (uint64_t)q.M * ssz <= PACK_MAX_ROWBYTES;
-            if (q.dst.bitcast)
-                ok = ok && ssz == dsz;
-            else
-                ok = ok && !(!s_int && d_int) && !(s_int && !d_int && ssz == 8);
-            if (!ok)
-                {
-                if (err)
-                    *err = "invalid unpack job (types, columns, alignment or pointers)";
-                return PGSD_ERROR_INVALID_ARGUMENT;
-                }
-            UnpackJob& j = args.j[args.n_jobs++];
-            j.src = q.src;
-            j.dst = q.dst.dst;
-            j.order = q.dst.order;
-            j.M = q.M;
-            j.ssz = ssz;
-            j.dsz = dsz;
-            j.kind = conv_kind(q.src_type, q.dst.dst_type, q.dst.bitcast);
-            j.dst_stride = q.dst.dst_stride;
-            j.dst_col0 = q.dst.dst_col0;
-            j.magic = q.M == 1 ? 0u : (uint32_t)(((1ull << 32) + q.M - 1) / q.M);
-            j.rowbytes = q.M * ssz;
-            max_rowbytes = std::max(max_rowbytes, j.rowbytes);
+            if (err)
+                *err = "invalid unpack job (types, columns, alignment or pointers)";
+            return PGSD_ERROR_INVALID_ARGUMENT;
             }
-        uint32_t tile = 16;
-        while (tile * 2 <= 1024 && (uint64_t)tile * 2 * max_rowbytes <= 32768)
-            tile <<= 1;
-        args.tile_rows = tile;
-        args.n_tiles = (N + tile - 1) / tile;
-        uint64_t blocks = args.n_tiles;
-        uint64_t cap = (uint64_t)num_cus() * 4;
-        if (blocks > cap)
-            blocks = cap;
-        size_t lds_bytes = ((size_t)tile * max_rowbytes + 15) & ~(size_t)15;
-        hipLaunchKernelGGL(unpack_tiles_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
+        UnpackJob j;
+        memset(&j, 0, sizeof(j));
+        j.src = q.src;
+        j.dst = q.dst.dst;
+        j.order = q.dst.order;
+        j.M = q.M;
+        j.ssz = ssz;
+        j.dsz = dsz;
+        j.kind = conv_kind(q.src_type, q.dst.dst_type, q.dst.bitcast);
+        j.dst_stride = q.dst.dst_stride;
+        j.dst_col0 = q.dst.dst_col0;
+        j.magic = q.M == 1 ? 0u : (uint32_t)(((1ull << 32) + q.M - 1) / q.M);
+        j.rowbytes = q.M * ssz;
+        all.push_back(j);
         }
+    // chunks of one destination array next to each other (their relative order is kept)
+    std::stable_sort(all.begin(), all.end(), [](const UnpackJob& a, const UnpackJob& b) { return (uintptr_t)a.dst < (uintptr_t)b.dst; });
+    std::vector<UnpackJob> batch;
+    uint32_t sum_rowbytes = 0;
+    for (size_t i = 0; i < all.size(); i++)
+        {
+        const UnpackJob& j = all[i];
+        // a chunk that rewrites columns an earlier chunk of the batch wrote goes to the next launch:
+        // "the later chunk wins" then holds by stream order
+        bool overlap = false;
+        for (const UnpackJob& b : batch)
+            if (b.dst == j.dst && j.dst_col0 < b.dst_col0 + b.M && b.dst_col0 < j.dst_col0 + j.M)
+                overlap = true;
+        if (!batch.empty()
+            && (overlap || batch.size() == UNPACK_MAX_JOBS || sum_rowbytes + j.rowbytes > UNPACK_MAX_SUM_ROWBYTES))
+            {
+            launch_unpack_batch(batch, N, stream);
+            batch.clear();
+            sum_rowbytes = 0;
+            }
+        batch.push_back(j);
+        sum_rowbytes += j.rowbytes;
+        }
+    if (!batch.empty())
+        launch_unpack_batch(batch, N, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         {

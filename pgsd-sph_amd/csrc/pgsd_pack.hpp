@@ -91,7 +91,11 @@ struct PackGenericArgs
 
 enum
     {
-    UNPACK_MAX_JOBS = 12
+    UNPACK_MAX_JOBS = 12,     // chunks per launch
+    UNPACK_MAX_GROUPS = 6,    // destination arrays assembled row-wise per launch
+    UNPACK_MAX_ROW_COLS = 16, // columns of such a destination row
+    UNPACK_LDS_BYTES = 49152, // LDS budget per workgroup
+    UNPACK_MAX_SUM_ROWBYTES = UNPACK_LDS_BYTES / 16 // chunk row bytes one launch can stage at the smallest tile
     };
 
 struct UnpackJob
@@ -101,6 +105,21 @@ struct UnpackJob
     const uint32_t* order; // scatter index or nullptr
     uint32_t M, ssz, dsz, kind;
     uint32_t dst_stride, dst_col0, magic, rowbytes; // rowbytes = M * ssz
+    uint32_t lds_off;      // where this chunk's tile sits in the workgroup's LDS
+    uint32_t in_group;     // 1: written by the row assembly of its destination array
+    };
+
+// A destination array every column of which is restored by chunks of the same launch (position.xyz
+// + type id into a Scalar4 array): its rows are assembled in registers and written with 16-byte stores.
+struct UnpackGroup
+    {
+    void* dst;
+    const uint32_t* order;
+    uint32_t stride, dsz;
+    uint32_t vec_shift; // log2(16-byte vectors per destination row)
+    uint32_t pad;
+    uint8_t col_job[UNPACK_MAX_ROW_COLS]; // per destination column: the chunk it comes from ...
+    uint8_t col_off[UNPACK_MAX_ROW_COLS]; // ... and the column inside that chunk
     };
 
 struct UnpackArgs
@@ -109,7 +128,10 @@ struct UnpackArgs
     uint64_t n_tiles;
     uint32_t tile_rows;
     uint32_t n_jobs;
+    uint32_t n_groups;
+    uint32_t pad;
     UnpackJob j[UNPACK_MAX_JOBS];
+    UnpackGroup g[UNPACK_MAX_GROUPS];
     };
 
 // Enqueue the unpack of `n_jobs` chunks of N rows each on `stream`. Returns a pgsd_error.

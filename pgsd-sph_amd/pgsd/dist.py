@@ -49,15 +49,28 @@ def init_from_torch(group=None, device=None, prefer_rccl=True):
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % device)
         if rank == 0:
             buf = (ctypes.c_uint8 * 128)()
-            rc = lib.pgsd_comm_rccl_unique_id(buf)
-            if rc != 0:
-                raise RuntimeError("pgsd_comm_rccl_unique_id failed: " + _lib.last_error())
-            uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+            if lib.pgsd_comm_rccl_unique_id(buf) == 0:
+                uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
         dist.broadcast(uid, src=0, group=group)
         host = bytes(uid.cpu().tolist())
+        if not any(host):  # rank 0 could not produce an id: all ranks leave together
+            raise RuntimeError("pgsd_comm_rccl_unique_id failed on rank 0: " + _lib.last_error())
         rc = lib.pgsd_comm_init_rccl(host, rank, size, int(device))
-        if rc != 0:
-            raise RuntimeError("pgsd_comm_init_rccl failed: " + _lib.last_error())
+        err = _lib.last_error() if rc != 0 else ""
+        if rc == 0:
+            # one real exchange before the communicator is trusted with file offsets
+            got = (ctypes.c_uint32 * size)()
+            mine = ctypes.c_uint32(rank)
+            rc = lib.pgsd_comm_allgather(ctypes.byref(mine), got, 4)
+            if rc != 0 or list(got) != list(range(size)):
+                err = "rccl self-check allgather returned %r: %s" % (list(got), _lib.last_error())
+                rc = rc or -1
+        # every rank takes the same decision, or the ranks would sit on different communicators
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda:%d" % device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            lib.pgsd_comm_finalize()
+            raise RuntimeError("pgsd_comm_init_rccl failed on at least one rank: " + (err or "(another rank)"))
         return "rccl"
 
     on_gpu = backend == "nccl"

@@ -88,6 +88,103 @@ def test_unpack_scatter_in_tag_order():
     assert got[order, :3].tobytes() == src.tobytes()
 
 
+def unpack_many(specs, N, keep):
+    """specs: (src_np, dst_tensor, M, col0, order, bitcast); ONE pgsd_unpack_fields call."""
+    from pgsd import _lib
+    jobs = (_lib.UnpackJob * len(specs))()
+    for i, (src_np, dst_t, M, col0, order, bitcast) in enumerate(specs):
+        src = dev(src_np.view(np.uint8).reshape(-1))
+        keep.append(src)
+        jobs[i].src = src.data_ptr()
+        jobs[i].src_type = G.type_id(src_np.dtype)
+        jobs[i].M = M
+        jobs[i].dst.dst = dst_t.data_ptr()
+        jobs[i].dst.order = order.data_ptr() if order is not None else None
+        jobs[i].dst.dst_type = G.type_id(str(dst_t.dtype)[6:])
+        jobs[i].dst.dst_stride = dst_t.shape[1] if dst_t.dim() == 2 else 1
+        jobs[i].dst.dst_col0 = col0
+        jobs[i].dst.bitcast = 1 if bitcast else 0
+    torch.cuda.synchronize()
+    rc = _lib.lib.pgsd_unpack_fields(len(specs), jobs, N, None)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N", [1, 15, 63, 1000, 1025, 70001])
+@pytest.mark.parametrize("use_order", [False, True])
+def test_unpack_one_launch_assembles_whole_rows(N, use_order):
+    """position+typeid -> pos4 and velocity+mass -> vel4 (16-byte rows assembled in registers),
+    image -> dense int32 rows (element path), all in one launch."""
+    rng = np.random.default_rng(N + 5)
+    pos = G.rand_array(rng, (N, 3), np.float32)
+    vel = G.rand_array(rng, (N, 3), np.float32)
+    mass = G.rand_array(rng, (N, 1), np.float32)
+    tid = rng.integers(0, 2 ** 32, size=(N, 1), dtype=np.uint64).astype(np.uint32)
+    img = rng.integers(-5, 6, size=(N, 3)).astype(np.int32)
+    order_np = rng.permutation(N).astype(np.int32) if use_order else np.arange(N, dtype=np.int32)
+    order = dev(order_np) if use_order else None
+    pos4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    vel4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    img3 = torch.zeros((N, 3), dtype=torch.int32, device="cuda")
+    keep = []
+    unpack_many([(pos, pos4, 3, 0, order, False), (vel, vel4, 3, 0, order, False), (img, img3, 3, 0, None, False),
+                 (tid, pos4, 1, 3, order, True), (mass, vel4, 1, 3, order, False)], N, keep)
+    p, v = pos4.cpu().numpy(), vel4.cpu().numpy()
+    assert p[order_np, :3].tobytes() == pos.tobytes()
+    assert p[order_np, 3].view(np.uint32).tobytes() == tid.tobytes()
+    assert v[order_np, :3].tobytes() == vel.tobytes() and v[order_np, 3].tobytes() == mass.tobytes()
+    assert img3.cpu().numpy().tobytes() == img.tobytes()
+
+
+def test_unpack_wide_rows_with_conversion():
+    """f32 chunks into a double4 array (32-byte rows), f64 + i32->f32 into float4, ints into 64-byte rows."""
+    N = 33_333
+    rng = np.random.default_rng(8)
+    pos = G.rand_array(rng, (N, 3), np.float32)
+    w = G.rand_array(rng, (N, 1), np.float32)
+    d4 = torch.zeros((N, 4), dtype=torch.float64, device="cuda")
+    vd = G.rand_array(rng, (N, 2), np.float64)
+    vi = rng.integers(-1000, 1000, size=(N, 2)).astype(np.int32)
+    f4 = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    a = rng.integers(-2 ** 31, 2 ** 31, size=(N, 5)).astype(np.int32)
+    b = rng.integers(-2 ** 31, 2 ** 31, size=(N, 3)).astype(np.int32)
+    i8 = torch.zeros((N, 8), dtype=torch.int64, device="cuda")
+    u16 = torch.zeros((N, 16), dtype=torch.int32, device="cuda")
+    c = rng.integers(0, 2 ** 16, size=(N, 16)).astype(np.uint16)
+    keep = []
+    unpack_many([(pos, d4, 3, 0, None, False), (w, d4, 1, 3, None, False),
+                 (vd, f4, 2, 0, None, False), (vi, f4, 2, 2, None, False),
+                 (b, i8, 3, 5, None, False), (a, i8, 5, 0, None, False),
+                 (c, u16, 16, 0, None, False)], N, keep)
+    got = d4.cpu().numpy()
+    assert (got[:, :3] == pos.astype(np.float64)).all() and (got[:, 3] == w[:, 0].astype(np.float64)).all()
+    got = f4.cpu().numpy()
+    assert got[:, :2].tobytes() == vd.astype(np.float32).tobytes() and (got[:, 2:] == vi.astype(np.float32)).all()
+    got = i8.cpu().numpy()
+    assert (got[:, :5] == a.astype(np.int64)).all() and (got[:, 5:] == b.astype(np.int64)).all()
+    assert (u16.cpu().numpy() == c.astype(np.int32)).all()
+
+
+def test_unpack_later_chunk_wins_and_many_jobs():
+    N = 5003
+    rng = np.random.default_rng(9)
+    first = G.rand_array(rng, (N, 4), np.float32)
+    second = G.rand_array(rng, (N, 2), np.float32)
+    dst = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    keep = []
+    unpack_many([(first, dst, 4, 0, None, False), (second, dst, 2, 1, None, False)], N, keep)
+    got = dst.cpu().numpy()
+    assert got[:, 1:3].tobytes() == second.tobytes() and got[:, 0].tobytes() == first[:, 0].tobytes()
+    assert got[:, 3].tobytes() == first[:, 3].tobytes()
+    # more chunks than one launch holds, rows too wide to stage together
+    srcs = [G.rand_array(rng, (N, 100 + i), np.float32) for i in range(15)]
+    dsts = [torch.zeros((N, 101 + i), dtype=torch.float32, device="cuda") for i in range(15)]
+    unpack_many([(s_, d_, s_.shape[1], 1, None, False) for s_, d_ in zip(srcs, dsts)], N, keep)
+    for s_, d_ in zip(srcs, dsts):
+        g_ = d_.cpu().numpy()
+        assert g_[:, 1:].tobytes() == s_.tobytes() and (g_[:, 0] == 0).all()
+
+
 def _write_file(path, N, frames=2):
     import pgsd.fl as fl
     rng = np.random.default_rng(17)
