@@ -111,9 +111,10 @@ def main():
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
     ap.add_argument("--separate-id", action="store_true", help="typeid from its own uint32 array instead of pos.w")
-    ap.add_argument("--schema", choices=["pvi", "sph"], default="pvi",
+    ap.add_argument("--schema", choices=["pvi", "sph", "union"], default="pvi",
                     help="pvi: position+velocity+typeid (headline); sph: the full PGSD-SPH particle schema, "
-                         "112 B/particle in 15 chunks (BASELINE config 4 workload)")
+                         "112 B/particle in 15 chunks; union: plus the upstream HOOMD attributes, 164 B/particle "
+                         "(BASELINE config 4 workloads)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -171,7 +172,7 @@ def main():
               ("particles/typeid", id_field)]
 
     payload_bpp, algo_bpp = PAYLOAD_BYTES_PER_PARTICLE, ALGO_BYTES_PER_PARTICLE
-    if args.schema == "sph":
+    if args.schema in ("sph", "union"):
         # hoomd.py:167-184: typeid, mass, body, position, velocity, slength, density, pressure, energy,
         # auxiliary1-4, image -- from HOOMD-SPH-style device arrays (Scalar4 / int3-as-int4 / int)
         dpe = torch.rand((N, 4), generator=g, device="cuda")                 # density, pressure, energy, slength
@@ -192,6 +193,21 @@ def main():
         fields.append(("particles/image", fl.DeviceField.from_tensor(img, columns=(0, 3))))
         payload_bpp, algo_bpp = 112, 224
         layout = "HOOMD-SPH device arrays (Scalar4 pos/vel/dpe/aux1-4, int4 image, int body), full SPH schema"
+    if args.schema == "union":
+        # BASELINE config 4: the SPH set plus the upstream HOOMD particle attributes (pgsd.tex:508-521):
+        # charge, diameter (Scalar arrays), moment_inertia (Scalar3), orientation, angmom (Scalar4)
+        charge = torch.randn((N,), generator=g, device="cuda")
+        diameter = torch.rand((N,), generator=g, device="cuda")
+        inertia = torch.rand((N, 3), generator=g, device="cuda")
+        orient = torch.randn((N, 4), generator=g, device="cuda")
+        angmom = torch.randn((N, 4), generator=g, device="cuda")
+        fields += [("particles/charge", fl.DeviceField.from_tensor(charge)),
+                   ("particles/diameter", fl.DeviceField.from_tensor(diameter)),
+                   ("particles/moment_inertia", fl.DeviceField.from_tensor(inertia)),
+                   ("particles/orientation", fl.DeviceField.from_tensor(orient)),
+                   ("particles/angmom", fl.DeviceField.from_tensor(angmom))]
+        payload_bpp, algo_bpp = 164, 328
+        layout = "HOOMD-SPH device arrays + upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom)"
 
     path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
     f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
