@@ -396,6 +396,86 @@ template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack
         }
     }
 
+// Software-pipelined form of the tiled kernel for launches with at most PF_GROUPS linear source
+// arrays whose tiles are at most PF_VECS x 256 vectors: the 16-byte loads of the NEXT tile are
+// issued into registers before the current tile is emitted, so that a workgroup has loads in
+// flight while it stores.  What it buys is the overlap of the read and the write phase when a
+// workgroup only sees one or two tiles (2^20 particles: every tile is resident at once and the
+// plain kernel runs "all loads, then all stores").
+#define PF_GROUPS 3
+#define PF_VECS 4
+template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_prefetch_kernel(const PackArgs args)
+    {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t TILE = args.tile_rows;
+    u32x4 r[PF_GROUPS * PF_VECS];
+
+    auto issue = [&](uint64_t tile)
+    {
+        const uint64_t row0 = tile * TILE;
+        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+#pragma unroll
+        for (uint32_t gi = 0; gi < PF_GROUPS; gi++)
+            {
+            if (gi >= args.n_groups)
+                break;
+            const PackGroup& g = args.g[gi];
+            const u32x4* gsrc = (const u32x4*)((const char*)g.src + row0 * g.rowbytes);
+            const uint32_t nvec = (rows * g.rowbytes) >> 4;
+#pragma unroll
+            for (uint32_t k = 0; k < PF_VECS; k++)
+                {
+                const uint32_t v = tid + k * PACK_THREADS;
+                if (v < nvec)
+                    r[gi * PF_VECS + k] = __builtin_nontemporal_load(gsrc + v);
+                }
+            }
+    };
+    auto commit = [&](uint64_t tile)
+    {
+        const uint64_t row0 = tile * TILE;
+        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+#pragma unroll
+        for (uint32_t gi = 0; gi < PF_GROUPS; gi++)
+            {
+            if (gi >= args.n_groups)
+                break;
+            const PackGroup& g = args.g[gi];
+            char* l = lds + g.lds_off;
+            const uint32_t nbytes = rows * g.rowbytes;
+            const uint32_t nvec = nbytes >> 4;
+#pragma unroll
+            for (uint32_t k = 0; k < PF_VECS; k++)
+                {
+                const uint32_t v = tid + k * PACK_THREADS;
+                if (v < nvec)
+                    *(u32x4*)(l + lds_skew<0>(v << 4)) = r[gi * PF_VECS + k];
+                }
+            // ragged end of the last tile
+            const char* gsrc = (const char*)g.src + row0 * g.rowbytes;
+            for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
+                l[lds_skew<0>(b)] = gsrc[b];
+            }
+    };
+
+    uint64_t tile = blockIdx.x;
+    if (tile < args.n_tiles)
+        issue(tile);
+    for (; tile < args.n_tiles; tile += gridDim.x)
+        {
+        const uint64_t row0 = tile * TILE;
+        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
+        commit(tile);
+        __syncthreads();
+        if (tile + gridDim.x < args.n_tiles)
+            issue(tile + gridDim.x);
+        for (uint32_t gi = 0; gi < args.n_groups; gi++)
+            emit_group<PACK_THREADS, MODE, 0>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
+        __syncthreads();
+        }
+    }
+
 // Wave-streaming kernel: every 64-lane wavefront owns a private PACK_WAVE_LDS-byte LDS
 // window and steps through `wave_rows`-row pieces dealt round-robin over all waves of the
 // grid; no workgroup barrier exists (LDS operations of one wave execute in program
@@ -877,9 +957,22 @@ static void launch_mode(bool waves, int var, unsigned blocks, size_t lds_bytes, 
         }
     }
 
-static void launch_variant(bool waves, int mode, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
-                           const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
+static void launch_variant(bool waves, bool prefetch, int mode, int var, unsigned blocks, size_t lds_bytes,
+                           hipStream_t stream, const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
     {
+    if (prefetch && !waves)
+        {
+        if (mode == PACK_MODE_W32)
+            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_W32>), dim3(blocks), dim3(PACK_THREADS),
+                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
+        else if (mode == PACK_MODE_F64_F32)
+            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_F64_F32>), dim3(blocks), dim3(PACK_THREADS),
+                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
+        else
+            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_GENERIC>), dim3(blocks), dim3(PACK_THREADS),
+                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
+        return;
+        }
     if (mode == PACK_MODE_W32)
         launch_mode<PACK_MODE_W32>(waves, var, blocks, lds_bytes, stream, args, ev_start, ev_stop);
     else if (mode == PACK_MODE_F64_F32)
@@ -891,6 +984,7 @@ static void launch_variant(bool waves, int mode, int var, unsigned blocks, size_
 struct PendingLaunch
     {
     bool waves;
+    bool prefetch;
     int mode, var;
     unsigned blocks;
     size_t lds_bytes;
@@ -1038,7 +1132,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t max_blocks = (N + 255) / 256;
             if (blocks > max_blocks)
                 blocks = max_blocks;
-            pending.push_back({true, mode, var, (unsigned)blocks, (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, args});
+            pending.push_back({true, false, mode, var, (unsigned)blocks, (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, args});
             }
         else
             {
@@ -1081,7 +1175,18 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t cap = (uint64_t)num_cus() * std::min<uint64_t>(per_cu, resident);
             if (blocks > cap)
                 blocks = cap;
-            pending.push_back({false, mode, var, (unsigned)blocks, lds_bytes, args});
+            // the software-pipelined kernel takes launches it has registers for: one batch, linear
+            // sources, tiles of at most PF_VECS x 256 vectors, default variant
+            bool prefetch = args.n_batches == 1 && args.n_groups <= PF_GROUPS && var == 0;
+            for (uint32_t k = 0; k < args.n_groups; k++)
+                prefetch = prefetch && args.g[k].order == nullptr
+                           && (size_t)tile * args.g[k].rowbytes <= (size_t)PF_VECS * PACK_THREADS * 16;
+            int want = -1; // -1: by size
+            if (const char* e = getenv("PGSD_PACK_PREFETCH"))
+                want = atoi(e);
+            if (want == 0 || (want < 0 && args.n_tiles > 2 * blocks))
+                prefetch = false;
+            pending.push_back({false, prefetch, mode, var, (unsigned)blocks, lds_bytes, args});
             }
         while (next < n_jobs && done[next])
             next++;
@@ -1093,7 +1198,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         const PendingLaunch& L = pending[i];
         hipEvent_t s0 = (!generic_used && i == 0) ? ev_start : nullptr;
         hipEvent_t s1 = (!generic_used && i + 1 == pending.size()) ? ev_stop : nullptr;
-        launch_variant(L.waves, L.mode, L.var, L.blocks, L.lds_bytes, stream, L.args, s0, s1);
+        launch_variant(L.waves, L.prefetch, L.mode, L.var, L.blocks, L.lds_bytes, stream, L.args, s0, s1);
         }
     if (ev_stop && (generic_used || pending.empty()))
         {

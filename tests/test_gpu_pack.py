@@ -251,10 +251,14 @@ def test_select_rows(N, p):
     assert (got[expect.size:] == -1).all()
 
 
-def test_full_size_pack_matches_independent_gpu_slicing():
+@pytest.mark.parametrize("prefetch", ["default", "1", "0"])
+def test_full_size_pack_matches_independent_gpu_slicing(prefetch, monkeypatch):
     """BASELINE size (10 M particles): compare against torch's own strided copy on the GPU
-    (an independent implementation), bit for bit, plus a checksum of checksums."""
-    N = 10_000_000
+    (an independent implementation), bit for bit, plus a checksum of checksums. Runs through the
+    plain tiled kernel and through the software-pipelined one (many tiles per workgroup)."""
+    if prefetch != "default":
+        monkeypatch.setenv("PGSD_PACK_PREFETCH", prefetch)
+    N = 10_000_000 if prefetch != "1" else 10_000_000 - 777     # ragged last tile for the pipelined loop
     g = torch.Generator(device="cuda").manual_seed(1234)
     pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
     vel = torch.randn((N, 4), generator=g, device="cuda")
