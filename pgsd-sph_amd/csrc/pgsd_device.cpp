@@ -256,10 +256,9 @@ class DevicePipeline
         {
         if (!m_ok)
             return PGSD_SUCCESS;
-            {
-            std::unique_lock<std::mutex> lk(m_mutex);
-            m_cv_done.wait(lk, [this] { return m_reads_outstanding == 0; });
-            }
+        std::unique_lock<std::mutex> lk(m_mutex);
+        m_cv_done.wait(lk, [this] { return m_reads_outstanding == 0; });
+        lk.unlock();
         (void)hipSetDevice(m_cfg.device);
         launch_pending_unpacks();
         hipError_t e = hipStreamSynchronize(m_copy_stream);

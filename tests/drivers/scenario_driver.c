@@ -247,7 +247,7 @@ int main(int argc, char** argv)
             int type = parse_type(tok[2], &sz);
             uint32_t M = (uint32_t)strtoul(tok[3], NULL, 10);
             int all = atoi(tok[4]);
-            uint64_t counts[1024];
+            uint64_t counts[1024] = {0};
             dist_counts(tok[5], counts);
             uint64_t N = counts[g_rank], Ng = 0, row0 = 0;
             for (int r = 0; r < g_size; r++)
