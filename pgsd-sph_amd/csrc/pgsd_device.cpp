@@ -278,7 +278,11 @@ class DevicePipeline
                 a.used = 0;
             }
         if (failed())
+            {
+            if (m_io_error && m_io_errno)
+                errno = m_io_errno;
             return m_io_error ? PGSD_ERROR_IO : PGSD_ERROR_DEVICE;
+            }
         return PGSD_SUCCESS;
         }
 
@@ -322,7 +326,11 @@ class DevicePipeline
             // let the writers finish what they hold before the caller tears anything down
             std::unique_lock<std::mutex> lk(m_mutex);
             m_cv_done.wait_for(lk, std::chrono::seconds(30), [this] { return m_outstanding == 0; });
+            {
+            if (m_io_error && m_io_errno)
+                errno = m_io_errno;
             return m_io_error ? PGSD_ERROR_IO : PGSD_ERROR_DEVICE;
+            }
             }
         return PGSD_SUCCESS;
         }
@@ -367,13 +375,14 @@ class DevicePipeline
         hipEvent_t packed;
         };
 
-    void fail(const std::string& msg, bool io = false)
+    void fail(const std::string& msg, bool io = false, int io_errno = 0)
         {
         std::lock_guard<std::mutex> g(m_mutex);
         if (m_error.empty())
             {
             m_error = msg;
             m_io_error = io;
+            m_io_errno = io_errno;
             }
         m_cv_done.notify_all();
         m_cv_slabs.notify_all();
@@ -688,7 +697,7 @@ class DevicePipeline
             int w = pwrite_locked(m_fd, s.host, n, foff, m_shared);
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (w != 0)
-                fail(std::string("pwrite: ") + strerror(-w), true);
+                fail(std::string("pwrite: ") + strerror(-w), true, -w);
             }
         release_slab(si);
         piece_done(n, ms);
@@ -737,6 +746,7 @@ class DevicePipeline
     bool m_stop = false;
     std::string m_error;
     bool m_io_error = false;
+    int m_io_errno = 0; // errno of the failed write (worker thread), handed to the caller's thread
     pgsd_device_stats m_stats = {};
     };
 

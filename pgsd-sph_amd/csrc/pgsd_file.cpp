@@ -162,6 +162,11 @@ struct Impl
     uint64_t idxbuf = DEFAULT_INDEX_ENTRIES_TO_BUFFER;
     bool dirty_data = false; // a direct/device chunk was written since the last flush
     bool inflight = false;   // an asynchronous end_frame left device chunks on their way to the file
+    // A write of THIS rank's rows failed in pgsd_write_chunk.  The call returned the error at once
+    // (as the reference does, pgsd.c:2229-2236), but per-particle chunks involve no collective, so
+    // the other ranks learn of it at the next flush: its status exchange reports it on every rank.
+    int sticky_rc = PGSD_SUCCESS;
+    int sticky_errno = 0;
     WriterPool* pool = nullptr;
     DevicePipeline* dev = nullptr;
     pgsd_device_config devcfg;
@@ -601,6 +606,7 @@ static int do_flush(Impl* s, bool async = false)
         }
 
     int local_rc = PGSD_SUCCESS;
+    int sticky_errno = 0;
     // device chunks of this rank must be in the file before the frame is sealed
     if (s->dev && async)
         s->inflight = true;
@@ -613,7 +619,18 @@ static int do_flush(Impl* s, bool async = false)
             {
             set_last_error(err);
             local_rc = drc;
+            if (drc == PGSD_ERROR_IO)
+                sticky_errno = errno; // of the pipeline's writer thread
             }
+        }
+    if (s->sticky_rc != PGSD_SUCCESS)
+        {
+        if (local_rc == PGSD_SUCCESS)
+            {
+            local_rc = s->sticky_rc;
+            sticky_errno = s->sticky_errno;
+            }
+        s->sticky_rc = PGSD_SUCCESS;
         }
     int rc = flush_name_buffer(s);
     if (rc != PGSD_SUCCESS && local_rc == PGSD_SUCCESS)
@@ -666,6 +683,8 @@ static int do_flush(Impl* s, bool async = false)
             }
         }
     s->dirty_data = false;
+    if (sticky_errno)
+        errno = sticky_errno;
     return agree_status(s, local_rc);
     }
 
@@ -1031,6 +1050,11 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
                 {
                 errno = -e;
                 rc = PGSD_ERROR_IO;
+                if (s->sticky_rc == PGSD_SUCCESS)
+                    {
+                    s->sticky_rc = rc;
+                    s->sticky_errno = -e;
+                    }
                 }
             }
         }
