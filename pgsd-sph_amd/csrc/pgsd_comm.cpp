@@ -8,6 +8,9 @@
 // pgsd_comm_set_default().
 #include "pgsd_internal.hpp"
 
+#include <new>
+#include <stdexcept>
+
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +35,45 @@ void set_last_error(const std::string& s)
 const char* last_error()
     {
     return g_last_error.c_str();
+    }
+
+int abi_guard() noexcept
+    {
+    try
+        {
+        throw; // the exception the entry point caught
+        }
+    catch (const std::bad_alloc&)
+        {
+        }
+    catch (const std::length_error&)
+        {
+        }
+    catch (const std::exception& e)
+        {
+        try
+            {
+            set_last_error(std::string("internal error: ") + e.what());
+            }
+        catch (...)
+            {
+            }
+        return PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    catch (...)
+        {
+        return PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    // an allocation the request (or a damaged file) asked for cannot be made: the reference's
+    // malloc-failure code (pgsd.c:1520)
+    try
+        {
+        set_last_error("memory allocation failed");
+        }
+    catch (...)
+        {
+        }
+    return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
     }
 
 // ---------------------------------------------------------------- self
@@ -136,23 +178,40 @@ static int comm_install(const pgsd_comm& c)
 using namespace pgsd_amd;
 
 extern "C" const char* pgsd_last_error_string(void)
+    try
     {
     return last_error();
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return nullptr;
+    }
 
 extern "C" int pgsd_comm_set_default(const struct pgsd_comm* comm)
+    try
     {
     if (!comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
         return PGSD_ERROR_INVALID_ARGUMENT;
     return comm_install(*comm);
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_init_self(void)
+    try
     {
     return comm_install(make_self());
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
+    try
     {
     if (!name || size < 1 || rank < 0 || rank >= size)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -246,8 +305,13 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
     pc.destroy = shm_destroy;
     return comm_install(pc);
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_init_from_env(void)
+    try
     {
     const char* r = getenv("PGSD_RANK");
     const char* n = getenv("PGSD_NRANKS");
@@ -267,35 +331,65 @@ extern "C" int pgsd_comm_init_from_env(void)
         }
     return pgsd_comm_init_self();
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_finalize(void)
+    try
     {
     return comm_install(make_self());
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_rank(void)
+    try
     {
     return default_comm().rank;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_size(void)
+    try
     {
     return default_comm().size;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_allgather(const void* send, void* recv, size_t bytes)
+    try
     {
     pgsd_comm c = default_comm();
     return c.allgather(c.ctx, send, recv, bytes) == 0 ? PGSD_SUCCESS : PGSD_ERROR_COMM;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_barrier(void)
+    try
     {
     pgsd_comm c = default_comm();
     return comm_barrier(c);
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_partition_rows(uint64_t n_local, uint64_t* row0, uint64_t* n_global, uint64_t* counts)
+    try
     {
     pgsd_comm c = default_comm();
     std::vector<uint64_t> all((size_t)c.size);
@@ -316,9 +410,14 @@ extern "C" int pgsd_partition_rows(uint64_t n_local, uint64_t* row0, uint64_t* n
         *n_global = total;
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 // reference pgsd.h:735 / pgsd.c:152-172: broadcast of one index entry from rank 0
 extern "C" void pgsd_bcast_index_entry(struct pgsd_index_entry* e)
+    try
     {
     if (!e)
         return;
@@ -326,4 +425,8 @@ extern "C" void pgsd_bcast_index_entry(struct pgsd_index_entry* e)
     std::vector<pgsd_index_entry> all((size_t)c.size);
     if (c.allgather(c.ctx, e, all.data(), sizeof(*e)) == 0)
         *e = all[0];
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
     }

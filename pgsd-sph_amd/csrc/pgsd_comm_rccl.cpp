@@ -142,6 +142,7 @@ static void rccl_destroy(void* p)
 using namespace pgsd_amd;
 
 extern "C" int pgsd_comm_rccl_unique_id(void* unique_id_128)
+    try
     {
     if (!unique_id_128)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -157,8 +158,13 @@ extern "C" int pgsd_comm_rccl_unique_id(void* unique_id_128)
     memcpy(unique_id_128, &id, sizeof(id));
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device)
+    try
     {
     if (!unique_id_128 || size < 1 || rank < 0 || rank >= size)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -199,4 +205,8 @@ extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size
     pc.barrier = nullptr; // 1-byte allgather
     pc.destroy = rccl_destroy;
     return pgsd_comm_set_default(&pc);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
     }

@@ -301,8 +301,11 @@ static bool entry_valid(const Impl* s, const pgsd_index_entry& e)
     // pgsd.c:414-450
     if (sizeof_type(e.type) == 0)
         return false;
-    size_t size = e.N * e.M * sizeof_type(e.type);
-    if ((uint64_t)(e.location + size) > (uint64_t)s->file_size)
+    // as pgsd.c:421-425, in arithmetic that a damaged entry cannot wrap around
+    if (e.location < 0 || e.location > s->file_size)
+        return false;
+    const unsigned __int128 size = (unsigned __int128)e.N * e.M * sizeof_type(e.type);
+    if (size > (unsigned __int128)(s->file_size - e.location))
         return false;
     if (e.frame >= s->header.index_allocated_entries)
         return false;
@@ -330,8 +333,9 @@ static int initialize_handle(Impl* s)
         return PGSD_ERROR_IO;
     s->file_size = (long long)st.st_size;
 
-    if (s->header.namelist_location + (PGSD_NAME_SIZE * s->header.namelist_allocated_entries)
-        > (uint64_t)s->file_size)
+    // pgsd.c:1558-1562; the products are formed so that a damaged header cannot wrap them around
+    if (s->header.namelist_location > (uint64_t)s->file_size
+        || s->header.namelist_allocated_entries > ((uint64_t)s->file_size - s->header.namelist_location) / PGSD_NAME_SIZE)
         return PGSD_ERROR_FILE_CORRUPT;
 
     // name list
@@ -361,8 +365,9 @@ static int initialize_handle(Impl* s)
     s->file_names.size = name_start;
 
     // index block, pgsd.c:602-707
-    if (s->header.index_location + sizeof(pgsd_index_entry) * s->header.index_allocated_entries
-        > (uint64_t)s->file_size)
+    if (s->header.index_location > (uint64_t)s->file_size
+        || s->header.index_allocated_entries
+               > ((uint64_t)s->file_size - s->header.index_location) / sizeof(pgsd_index_entry))
         return PGSD_ERROR_FILE_CORRUPT;
     if (s->header.index_allocated_entries == 0)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -862,18 +867,31 @@ using namespace pgsd_amd;
 // ============================================================================ C ABI
 
 extern "C" uint32_t pgsd_make_version(unsigned int major, unsigned int minor)
+    try
     {
     return make_version(major, minor);
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" size_t pgsd_sizeof_type(enum pgsd_type type)
+    try
     {
     return sizeof_type((uint32_t)type);
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
     }
 
 extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fname, const char* application,
                                     const char* schema, uint32_t schema_version,
                                     enum pgsd_open_flag flags, int exclusive_create)
+    try
     {
     // pgsd.c:1710-1773
     if (!handle || !fname || !application || !schema)
@@ -920,8 +938,13 @@ extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fnam
     publish(handle, s);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags)
+    try
     {
     // pgsd.c:1775-1812
     if (!handle || !fname)
@@ -948,8 +971,13 @@ extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgs
     publish(handle, s);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_close(struct pgsd_handle* handle)
+    try
     {
     // pgsd.c:1814-1914
     if (!handle)
@@ -978,8 +1006,13 @@ extern "C" int pgsd_close(struct pgsd_handle* handle)
         return PGSD_ERROR_IO;
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_end_frame(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -988,8 +1021,13 @@ extern "C" int pgsd_end_frame(struct pgsd_handle* handle)
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_end_frame_async(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -998,8 +1036,13 @@ extern "C" int pgsd_end_frame_async(struct pgsd_handle* handle)
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_frame_sync(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1013,8 +1056,13 @@ extern "C" int pgsd_frame_sync(struct pgsd_handle* handle)
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_flush(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1023,10 +1071,15 @@ extern "C" int pgsd_flush(struct pgsd_handle* handle)
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, enum pgsd_type type, uint64_t N,
                                 uint32_t M, uint64_t N_global, uint32_t M_global, uint64_t offset,
                                 uint64_t global_size, bool all, uint8_t flags, const void* data)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1061,21 +1114,38 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" uint64_t pgsd_get_nframes(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     return s ? s->cur_frame : 0;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" uint64_t pgsd_get_nnames(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     return s ? s->file_n_names : 0;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" const struct pgsd_index_entry* pgsd_find_chunk(struct pgsd_handle* handle, uint64_t frame,
                                                           const char* name)
+    try
     {
     // pgsd.c:2295-2434; valid on every rank because the index is replicated
     Impl* s = impl_of(handle);
@@ -1132,9 +1202,15 @@ extern "C" const struct pgsd_index_entry* pgsd_find_chunk(struct pgsd_handle* ha
             return &s->file_index[(size_t)cur];
     return NULL;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return nullptr;
+    }
 
 extern "C" int pgsd_read_chunk(struct pgsd_handle* handle, void* data, const struct pgsd_index_entry* chunk,
                                uint64_t N, uint32_t M, uint32_t offset, bool all)
+    try
     {
     // pgsd.c:2436-2537
     Impl* s = impl_of(handle);
@@ -1169,9 +1245,14 @@ extern "C" int pgsd_read_chunk(struct pgsd_handle* handle, void* data, const str
     pread_some(s->fd, data, size, c.location + (long long)stride);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" const char* pgsd_find_matching_chunk_name(struct pgsd_handle* handle, const char* match,
                                                      const char* prev)
+    try
     {
     // pgsd.c:2557-2641
     Impl* s = impl_of(handle);
@@ -1221,14 +1302,26 @@ extern "C" const char* pgsd_find_matching_chunk_name(struct pgsd_handle* handle,
         }
     return NULL;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return nullptr;
+    }
 
 extern "C" uint64_t pgsd_get_maximum_write_buffer_size(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     return s ? s->maxbuf : 0;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" int pgsd_set_maximum_write_buffer_size(struct pgsd_handle* handle, uint64_t size)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s || size == 0)
@@ -1237,14 +1330,25 @@ extern "C" int pgsd_set_maximum_write_buffer_size(struct pgsd_handle* handle, ui
     publish(handle, s);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" uint64_t pgsd_get_index_entries_to_buffer(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     return s ? s->idxbuf : 0;
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" int pgsd_set_index_entries_to_buffer(struct pgsd_handle* handle, uint64_t number)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s || number == 0)
@@ -1253,10 +1357,15 @@ extern "C" int pgsd_set_index_entries_to_buffer(struct pgsd_handle* handle, uint
     publish(handle, s);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 // ---------------------------------------------------------------------------- device path
 
 extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s || !cfg)
@@ -1276,6 +1385,10 @@ extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pg
     s->devcfg = *cfg;
     s->devcfg_set = true;
     return ensure_device(s);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
     }
 
 static int check_field(const pgsd_field_desc* f, uint32_t dst_type, uint32_t M)
@@ -1299,6 +1412,7 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
                                        uint64_t N, uint32_t M, uint64_t N_global, uint32_t M_global,
                                        uint64_t offset, uint64_t global_size, bool all, uint8_t flags,
                                        const struct pgsd_field_desc* src)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1343,10 +1457,15 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_chunks,
                                         const struct pgsd_chunk_req* reqs, uint64_t N, uint64_t N_global,
                                         uint64_t offset_rows)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s || !reqs || n_chunks == 0)
@@ -1394,9 +1513,14 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
     publish(handle, s);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_read_chunk_device(struct pgsd_handle* handle, const struct pgsd_index_entry* chunk, uint64_t N,
                                       uint64_t row_offset, const struct pgsd_field_dst* dst)
+    try
     {
     // device twin of pgsd_read_chunk's all==true slab read (pgsd.c:2498-2534)
     Impl* s = impl_of(handle);
@@ -1438,8 +1562,13 @@ extern "C" int pgsd_read_chunk_device(struct pgsd_handle* handle, const struct p
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_device_wait_read(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1452,8 +1581,13 @@ extern "C" int pgsd_device_wait_read(struct pgsd_handle* handle)
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* stream)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1464,8 +1598,13 @@ extern "C" int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* s
     device_pipeline_set_source_stream(s->dev, stream);
     return PGSD_SUCCESS;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_device_wait_packed(struct pgsd_handle* handle)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s)
@@ -1478,8 +1617,13 @@ extern "C" int pgsd_device_wait_packed(struct pgsd_handle* handle)
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_device_get_stats(struct pgsd_handle* handle, struct pgsd_device_stats* out, int reset)
+    try
     {
     Impl* s = impl_of(handle);
     if (!s || !out)
@@ -1488,4 +1632,8 @@ extern "C" int pgsd_device_get_stats(struct pgsd_handle* handle, struct pgsd_dev
     if (s->dev)
         device_pipeline_stats(s->dev, out, reset);
     return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
     }

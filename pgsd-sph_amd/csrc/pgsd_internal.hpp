@@ -13,6 +13,9 @@ namespace pgsd_amd
     {
 void set_last_error(const std::string& s);
 const char* last_error();
+// Called from the catch-all of every C-ABI entry point (function-try-blocks): no C++ exception
+// crosses the boundary.  Maps the exception in flight to a pgsd_error and records its text.
+int abi_guard() noexcept;
 pgsd_comm default_comm();
 
 inline int comm_barrier(const pgsd_comm& c)

@@ -1378,6 +1378,7 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
 using namespace pgsd_amd;
 
 extern "C" int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job* jobs, uint64_t N, void* stream)
+    try
     {
     if (n_jobs > 0 && !jobs)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -1392,8 +1393,13 @@ extern "C" int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job*
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_device_available(void)
+    try
     {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess)
@@ -1403,8 +1409,13 @@ extern "C" int pgsd_device_available(void)
         }
     return n > 0 ? 1 : 0;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream)
+    try
     {
     if (n_jobs > 0 && !jobs)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -1419,8 +1430,13 @@ extern "C" int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* job
         set_last_error(err);
     return rc;
     }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" size_t pgsd_select_workspace_bytes(uint64_t N)
+    try
     {
     uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
     if (n_blocks == 0)
@@ -1428,9 +1444,15 @@ extern "C" size_t pgsd_select_workspace_bytes(uint64_t N)
     // block_counts (u32) rounded to 8 bytes + block_offsets (u64)
     return (size_t)(((n_blocks * 4 + 7) & ~7ull) + n_blocks * 8);
     }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
 
 extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
                                 void* workspace, void* stream_)
+    try
     {
     if (!out_count || !workspace || (N > 0 && (!flags || !out_index)) || N >= (1ull << 32))
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -1463,4 +1485,8 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
         return PGSD_ERROR_DEVICE;
         }
     return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
     }
