@@ -138,3 +138,49 @@ def test_file_the_reference_leaves_short_is_reported_not_hung(tmp_path):
     assert p_log == ["rc line=8 cmd=open rc=-5"]
     with open(o_path, "rb") as a, open(p_path, "rb") as b:
         assert a.read() == b.read()
+
+
+def long_run_script(n_frames):
+    """thousands of short frames: the on-disk index is relocated and doubled again and again
+    (pgsd.c:965-1091), names keep arriving, buffered and direct chunks alternate"""
+    lines = ["create long_run hoomd 1 4 rw 0"]
+    for i in range(n_frames):
+        lines += ["seed %d" % (i + 1),
+                  "chunk configuration/step u64 1 0 same:1",
+                  "chunk particles/N u32 1 0 same:1",
+                  "chunk particles/position f32 3 1 even:%d" % (37 + i % 5)]
+        if i % 3 == 0:
+            lines.append("chunk log/extra%d f64 2 0 same:1" % (i % 50))
+        lines.append("end_frame")
+        if i in (n_frames // 3, 2 * n_frames // 3):
+            lines += ["close", "open append" if i < n_frames // 2 else "open rw"]
+    lines += ["dump", "close", "open ro", "dump", "find %d particles/position" % (n_frames - 1), "close"]
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_long_run_product_equals_oracle(P, tmp_path):
+    scn = tmp_path / "long.scn"
+    scn.write_text(long_run_script(12000))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "product.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    p_log = product.run_driver(str(scn), p_path, P, timeout=600)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
+    assert p_log == o_log
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not have_ref(), reason="compiled reference (oracle/_ref) or MPICH not present")
+@pytest.mark.parametrize("P", [1, 2])
+def test_long_run_oracle_equals_compiled_reference(P, tmp_path):
+    scn = tmp_path / "long.scn"
+    scn.write_text(long_run_script(3000))
+    r_path, o_path = str(tmp_path / "ref.gsd"), str(tmp_path / "oracle.gsd")
+    out = subprocess.run([MPIEXEC, "-n", str(P), REF_DRIVER, str(scn), r_path], capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-500:]
+    r_log = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    o_log = S.run_oracle(str(scn), o_path, P)
+    with open(r_path, "rb") as a, open(o_path, "rb") as b:
+        assert a.read() == b.read()
+    assert o_log == r_log
