@@ -303,3 +303,57 @@ def test_full_size_frame_matches_oracle_file(tmp_path):
         for p in (mine, ref):
             if os.path.exists(p):
                 os.unlink(p)
+
+
+def test_two_trajectories_written_concurrently_from_two_threads(tmp_path):
+    """A simulation keeps a trajectory and a restart file open at once; here two threads drive
+    two handles (two device pipelines) at the same time, asynchronous sealing included. Each file
+    must equal the oracle's file for its own frames."""
+    import threading
+    import pgsd.fl as fl
+    results = {}
+
+    def writer(tag, N, n_frames, async_seal):
+        try:
+            rng = np.random.default_rng(len(tag) + N)
+            mine = str(tmp_path / (tag + ".gsd"))
+            f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+            f.configure_device(slab_bytes=256 * 1024, n_slabs=4)
+            frames = []
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for i in range(n_frames):
+                    pos = G.rand_array(rng, (N, 4), np.float32)
+                    vel = G.rand_array(rng, (N, 4), np.float32)
+                    dpos, dvel = dev(pos), dev(vel)
+                    step = np.array([i], dtype=np.uint64)
+                    f.write_chunk('configuration/step', step, write_all=False)
+                    f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
+                                    ('particles/typeid', fl.DeviceField.from_tensor(dpos, columns=(3, 4), out_dtype=np.uint32,
+                                                                                   bitcast=True)),
+                                    ('particles/velocity', fl.DeviceField.from_tensor(dvel, columns=(0, 3)))],
+                                   offset=np.array([N]))
+                    f.end_frame(wait=not async_seal)
+                    frames.append([('configuration/step', 4, 1, False, [step.reshape(1, 1)]),
+                                   ('particles/position', 9, 3, True, [G.oracle_pack(pos, 3)]),
+                                   ('particles/typeid', 3, 1, True, [G.oracle_pack(pos, 1, col0=3, out_dtype=np.uint32, bitcast=True)]),
+                                   ('particles/velocity', 9, 3, True, [G.oracle_pack(vel, 3)])])
+                f.close()
+            results[tag] = (mine, frames)
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            results[tag] = e
+
+    threads = [threading.Thread(target=writer, args=("trajectory", 40_003, 6, True)),
+               threading.Thread(target=writer, args=("restart", 150_001, 3, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for tag in ("trajectory", "restart"):
+        assert not isinstance(results[tag], Exception), results[tag]
+        mine, frames = results[tag]
+        ref = str(tmp_path / (tag + "_oracle.gsd"))
+        _oracle_frames(ref, 1, frames)
+        with open(mine, 'rb') as a, open(ref, 'rb') as b:
+            assert a.read() == b.read(), tag
