@@ -9,6 +9,7 @@
 #include "pgsd_internal.hpp"
 
 #include <new>
+#include <signal.h>
 #include <stdexcept>
 
 #include <cerrno>
@@ -112,6 +113,7 @@ struct ShmSegment
     {
     volatile uint32_t ready;
     uint32_t size;
+    volatile int32_t creator_pid; // rank 0's process: a segment whose creator is gone is a crashed run's
     pthread_barrier_t barrier;
     char pad[64];
     // followed by size * SHM_SLOT_BYTES slot bytes
@@ -210,13 +212,8 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
-    try
+static int shm_attach(const char* name, int rank, int size, int attempt)
     {
-    if (!name || size < 1 || rank < 0 || rank >= size)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    if (size == 1)
-        return pgsd_comm_init_self();
     std::string nm = name[0] == '/' ? name : std::string("/") + name;
     size_t bytes = sizeof(ShmSegment) + (size_t)size * SHM_SLOT_BYTES;
     int fd = -1;
@@ -271,6 +268,7 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
         pthread_barrier_init(&seg->barrier, &attr, (unsigned)size);
         pthread_barrierattr_destroy(&attr);
         seg->size = (uint32_t)size;
+        seg->creator_pid = (int32_t)getpid();
         __sync_synchronize();
         seg->ready = SHM_MAGIC;
         }
@@ -281,6 +279,20 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
         while (seg->ready != SHM_MAGIC && tries++ < 60000)
             nanosleep(&ts, NULL);
         __sync_synchronize();
+        if (seg->ready == SHM_MAGIC && seg->creator_pid > 0 && kill((pid_t)seg->creator_pid, 0) != 0 && errno == ESRCH)
+            {
+            // the segment of a crashed run under the same name, opened before this run's rank 0
+            // replaced it: drop it and look again
+            munmap(m, bytes);
+            if (attempt < 200)
+                {
+                struct timespec nap = {0, 10000000};
+                nanosleep(&nap, NULL);
+                return shm_attach(name, rank, size, attempt + 1);
+                }
+            set_last_error("shm segment " + nm + " belongs to a process that no longer exists");
+            return PGSD_ERROR_COMM;
+            }
         if (seg->ready != SHM_MAGIC || seg->size != (uint32_t)size)
             {
             munmap(m, bytes);
@@ -304,6 +316,16 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
     pc.barrier = shm_barrier;
     pc.destroy = shm_destroy;
     return comm_install(pc);
+    }
+
+extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
+    try
+    {
+    if (!name || size < 1 || rank < 0 || rank >= size)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (size == 1)
+        return pgsd_comm_init_self();
+    return shm_attach(name, rank, size, 0);
     }
 catch (...)
     {

@@ -1,0 +1,47 @@
+"""The /dev/shm communicator survives what a crashed earlier run leaves behind."""
+import os
+import subprocess
+import sys
+import time
+import uuid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %r)
+import pgsd.dist as d
+d.init_shm(sys.argv[1], int(sys.argv[2]), 2)
+if sys.argv[3] == "crash":
+    os._exit(0)          # no finalize: rank 0 never unlinks the segment
+c, row0, n = d.partition_rows(10 + int(sys.argv[2]))
+print(int(sys.argv[2]), [int(x) for x in c], row0, n)
+d.finalize()
+''' % os.path.join(ROOT, "pgsd-sph_amd")
+
+
+def test_stale_segment_of_a_crashed_run_is_not_joined():
+    name = "pgsd_stale_%s" % uuid.uuid4().hex[:10]
+    try:
+        ps = [subprocess.Popen([sys.executable, "-c", CHILD, name, str(r), "crash"]) for r in (0, 1)]
+        for p in ps:
+            assert p.wait(timeout=120) == 0
+        assert os.path.exists("/dev/shm/" + name)              # the crashed run's segment
+        # the next run under the same name: rank 1 arrives a second before rank 0 and finds the old segment
+        p1 = subprocess.Popen([sys.executable, "-c", CHILD, name, "1", "run"], stdout=subprocess.PIPE)
+        time.sleep(1.0)
+        p0 = subprocess.Popen([sys.executable, "-c", CHILD, name, "0", "run"], stdout=subprocess.PIPE)
+        try:
+            out0 = p0.communicate(timeout=120)[0].decode().strip()
+            out1 = p1.communicate(timeout=120)[0].decode().strip()
+        finally:
+            for p in (p0, p1):
+                if p.poll() is None:
+                    p.kill()
+        assert out0 == "0 [10, 11] 0 21" and out1 == "1 [10, 11] 10 21"
+        assert not os.path.exists("/dev/shm/" + name)
+    finally:
+        try:
+            os.unlink("/dev/shm/" + name)
+        except OSError:
+            pass
