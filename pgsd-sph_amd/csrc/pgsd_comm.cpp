@@ -109,12 +109,22 @@ enum
     SHM_MAGIC = 0x50475344 // "PGSD"
     };
 
+enum
+    {
+    SHM_MAX_RANKS = 1024
+    };
+
 struct ShmSegment
     {
     volatile uint32_t ready;
     uint32_t size;
     volatile int32_t creator_pid; // rank 0's process: a segment whose creator is gone is a crashed run's
-    pthread_barrier_t barrier;
+    // sense-reversing barrier on plain atomics: waiters poll (spin, then sleep), which lets them
+    // notice a peer that died instead of waiting for it forever as a futex barrier (or MPI) would
+    uint32_t arrived;
+    uint32_t generation;
+    uint32_t broken;
+    int32_t pids[SHM_MAX_RANKS];
     char pad[64];
     // followed by size * SHM_SLOT_BYTES slot bytes
     };
@@ -128,11 +138,74 @@ struct ShmCtx
     int rank, size;
     };
 
+// no such process, or a zombie nobody has reaped yet
+static bool process_gone(int32_t pid)
+    {
+    if (kill((pid_t)pid, 0) != 0)
+        return errno == ESRCH;
+    char path[64], buf[512];
+    snprintf(path, sizeof(path), "/proc/%d/stat", (int)pid);
+    FILE* f = fopen(path, "r");
+    if (!f)
+        return false;
+    size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char* close_paren = strrchr(buf, ')'); // "pid (comm) S ..."
+    return close_paren && close_paren[1] == ' ' && (close_paren[2] == 'Z' || close_paren[2] == 'X');
+    }
+
+static bool shm_peer_gone(ShmCtx* c)
+    {
+    for (int r = 0; r < c->size; r++)
+        {
+        int32_t pid = __atomic_load_n(&c->seg->pids[r], __ATOMIC_ACQUIRE);
+        if (pid > 0 && r != c->rank && process_gone(pid))
+            return true;
+        }
+    return false;
+    }
+
 static int shm_barrier(void* p)
     {
     ShmCtx* c = (ShmCtx*)p;
-    int rv = pthread_barrier_wait(&c->seg->barrier);
-    return (rv == 0 || rv == PTHREAD_BARRIER_SERIAL_THREAD) ? 0 : -1;
+    ShmSegment* seg = c->seg;
+    if (__atomic_load_n(&seg->broken, __ATOMIC_ACQUIRE))
+        return -1;
+    const uint32_t gen = __atomic_load_n(&seg->generation, __ATOMIC_ACQUIRE);
+    if (__atomic_add_fetch(&seg->arrived, 1, __ATOMIC_ACQ_REL) == (uint32_t)c->size)
+        {
+        __atomic_store_n(&seg->arrived, 0, __ATOMIC_RELAXED);
+        __atomic_add_fetch(&seg->generation, 1, __ATOMIC_RELEASE);
+        return 0;
+        }
+    uint32_t spins = 0;
+    long sleep_ns = 20000;
+    double slept = 0, next_check = 0.25;
+    while (__atomic_load_n(&seg->generation, __ATOMIC_ACQUIRE) == gen)
+        {
+        if (++spins < 2000)
+            {
+            __builtin_ia32_pause();
+            continue;
+            }
+        struct timespec ts = {0, sleep_ns};
+        nanosleep(&ts, NULL);
+        slept += sleep_ns * 1e-9;
+        if (sleep_ns < 1000000)
+            sleep_ns *= 2;
+        if (slept >= next_check)
+            {
+            next_check = slept + 0.25;
+            if (__atomic_load_n(&seg->broken, __ATOMIC_ACQUIRE) || shm_peer_gone(c))
+                {
+                __atomic_store_n(&seg->broken, 1, __ATOMIC_RELEASE);
+                set_last_error("a rank of the shm communicator is gone (process exited without pgsd_comm_finalize)");
+                return -1;
+                }
+            }
+        }
+    return 0;
     }
 
 static int shm_allgather(void* p, const void* send, void* recv, size_t bytes)
@@ -161,7 +234,8 @@ static void shm_destroy(void* p)
     {
     ShmCtx* c = (ShmCtx*)p;
     // everyone is past its last use before rank 0 removes the name
-    pthread_barrier_wait(&c->seg->barrier);
+    (void)shm_barrier(p);
+    __atomic_store_n(&c->seg->pids[c->rank], 0, __ATOMIC_RELEASE); // leaving in good order
     munmap((void*)c->seg, c->map_bytes);
     if (c->rank == 0)
         shm_unlink(c->name.c_str());
@@ -211,6 +285,11 @@ catch (...)
     {
         return pgsd_amd::abi_guard();
     }
+
+enum
+    {
+    SHM_RETRY = 1
+    };
 
 static int shm_attach(const char* name, int rank, int size, int attempt)
     {
@@ -262,11 +341,10 @@ static int shm_attach(const char* name, int rank, int size, int attempt)
     ShmSegment* seg = (ShmSegment*)m;
     if (rank == 0)
         {
-        pthread_barrierattr_t attr;
-        pthread_barrierattr_init(&attr);
-        pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
-        pthread_barrier_init(&seg->barrier, &attr, (unsigned)size);
-        pthread_barrierattr_destroy(&attr);
+        seg->arrived = 0;
+        seg->generation = 0;
+        seg->broken = 0;
+        memset((void*)seg->pids, 0, sizeof(seg->pids));
         seg->size = (uint32_t)size;
         seg->creator_pid = (int32_t)getpid();
         __sync_synchronize();
@@ -279,17 +357,13 @@ static int shm_attach(const char* name, int rank, int size, int attempt)
         while (seg->ready != SHM_MAGIC && tries++ < 60000)
             nanosleep(&ts, NULL);
         __sync_synchronize();
-        if (seg->ready == SHM_MAGIC && seg->creator_pid > 0 && kill((pid_t)seg->creator_pid, 0) != 0 && errno == ESRCH)
+        if (seg->ready == SHM_MAGIC && seg->creator_pid > 0 && process_gone(seg->creator_pid))
             {
             // the segment of a crashed run under the same name, opened before this run's rank 0
             // replaced it: drop it and look again
             munmap(m, bytes);
-            if (attempt < 200)
-                {
-                struct timespec nap = {0, 10000000};
-                nanosleep(&nap, NULL);
-                return shm_attach(name, rank, size, attempt + 1);
-                }
+            if (attempt < 6000) // about a minute, like the wait for the segment itself
+                return SHM_RETRY;
             set_last_error("shm segment " + nm + " belongs to a process that no longer exists");
             return PGSD_ERROR_COMM;
             }
@@ -300,6 +374,7 @@ static int shm_attach(const char* name, int rank, int size, int attempt)
             return PGSD_ERROR_COMM;
             }
         }
+    __atomic_store_n(&seg->pids[rank], (int32_t)getpid(), __ATOMIC_RELEASE);
     ShmCtx* c = new ShmCtx;
     c->seg = seg;
     c->slots = (char*)m + sizeof(ShmSegment);
@@ -325,7 +400,19 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (size == 1)
         return pgsd_comm_init_self();
-    return shm_attach(name, rank, size, 0);
+    if (size > SHM_MAX_RANKS)
+        {
+        set_last_error("the shm communicator takes at most 1024 ranks");
+        return PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    for (int attempt = 0;; attempt++)
+        {
+        int rc = shm_attach(name, rank, size, attempt);
+        if (rc != SHM_RETRY)
+            return rc;
+        struct timespec nap = {0, 10000000};
+        nanosleep(&nap, NULL);
+        }
     }
 catch (...)
     {

@@ -13,6 +13,7 @@ sys.path.insert(0, %r)
 import pgsd.dist as d
 d.init_shm(sys.argv[1], int(sys.argv[2]), 2)
 if sys.argv[3] == "crash":
+    d.partition_rows(1)  # both ranks are attached
     os._exit(0)          # no finalize: rank 0 never unlinks the segment
 c, row0, n = d.partition_rows(10 + int(sys.argv[2]))
 print(int(sys.argv[2]), [int(x) for x in c], row0, n)
@@ -40,6 +41,46 @@ def test_stale_segment_of_a_crashed_run_is_not_joined():
                     p.kill()
         assert out0 == "0 [10, 11] 0 21" and out1 == "1 [10, 11] 10 21"
         assert not os.path.exists("/dev/shm/" + name)
+    finally:
+        try:
+            os.unlink("/dev/shm/" + name)
+        except OSError:
+            pass
+
+
+PEER_DIES = r'''
+import sys, os, time
+sys.path.insert(0, %r)
+import pgsd.dist as d
+rank = int(sys.argv[2])
+d.init_shm(sys.argv[1], rank, 2)
+d.partition_rows(5)                   # one good exchange
+if rank == 1:
+    os._exit(0)                       # dies without a word
+t0 = time.time()
+try:
+    d.partition_rows(5)
+    print("NO ERROR")
+except RuntimeError as e:
+    print("error after %%.1f s: %%s" %% (time.time() - t0, e))
+d.finalize()
+''' % os.path.join(ROOT, "pgsd-sph_amd")
+
+
+def test_a_dead_peer_is_an_error_not_a_hang():
+    """MPI (and a futex barrier) would wait forever for the rank that is gone; the polling barrier
+    of the shm communicator checks on its peers while it waits."""
+    name = "pgsd_dead_%s" % uuid.uuid4().hex[:10]
+    try:
+        ps = [subprocess.Popen([sys.executable, "-c", PEER_DIES, name, str(r)], stdout=subprocess.PIPE) for r in (0, 1)]
+        try:
+            out0 = ps[0].communicate(timeout=60)[0].decode().strip()
+            ps[1].wait(timeout=60)
+        finally:
+            for p in ps:
+                if p.poll() is None:
+                    p.kill()
+        assert out0.startswith("error after") and "gone" in out0, out0
     finally:
         try:
             os.unlink("/dev/shm/" + name)
