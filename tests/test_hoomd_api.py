@@ -183,3 +183,82 @@ def test_append_to_existing_trajectory(tmp_gsd):
     with hoomd.open(tmp_gsd, 'r') as t:
         assert [s.configuration.step for s in t] == [0, 100, 200]
         np.testing.assert_array_equal(t[2].particles.density, np.arange(7) * 0.5 + 2)
+
+
+FIELDS = {'typeid': (np.uint32, 1), 'mass': (np.float32, 1), 'body': (np.int32, 1), 'position': (np.float32, 3),
+          'velocity': (np.float32, 3), 'slength': (np.float32, 1), 'density': (np.float32, 1),
+          'pressure': (np.float32, 1), 'energy': (np.float32, 1), 'auxiliary1': (np.float32, 3),
+          'auxiliary4': (np.float32, 3), 'image': (np.int32, 3)}
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trajectories_read_back_what_was_meant(seed, tmp_gsd):
+    """Model check of the elision rules (hoomd.py:654-694) and the reader's fall-backs
+    (hoomd.py:724-902): whatever mix of set / unset / default-valued / frame-0-valued attributes
+    and particle counts a trajectory has, frame i reads back as: the value set in frame i, else
+    frame 0's value when the particle count is the same, else the default."""
+    rng = np.random.default_rng(seed)
+    defaults = hoomd.ParticleData._default_value
+    n_frames = int(rng.integers(2, 7))
+    N0 = int(rng.integers(1, 9))
+    provided = []
+    with hoomd.open(tmp_gsd, 'w') as t:
+        for i in range(n_frames):
+            N = N0 if rng.random() < 0.7 else int(rng.integers(1, 9))
+            fr = hoomd.Frame()
+            fr.particles.N = N
+            rec = {'N': N}
+            if rng.random() < 0.8:
+                fr.configuration.step = rec['step'] = int(rng.integers(0, 1000))
+            if rng.random() < 0.5:
+                fr.configuration.box = rec['box'] = [float(x) for x in rng.integers(1, 9, 3)] + [0, 0, 0]
+            for name, (dt, M) in FIELDS.items():
+                r = rng.random()
+                if r < 0.35:
+                    continue                                                    # unset
+                shape = (N,) if M == 1 else (N, M)
+                if r < 0.5:                                                     # the default value, spelled out
+                    val = np.empty(shape, dtype=dt)
+                    val[...] = defaults[name]
+                elif r < 0.65 and provided and name in provided[0] and provided[0]['N'] == N:
+                    val = provided[0][name].copy()                              # same as frame 0
+                else:
+                    val = rng.integers(0, 5, size=shape).astype(dt)
+                setattr(fr.particles, name, val)
+                rec[name] = val
+            if rng.random() < 0.4:
+                fr.log['e'] = rec['log/e'] = np.array([float(rng.integers(0, 100))])
+            t.append(fr)
+            provided.append(rec)
+
+    def expected(i, name):
+        if name in provided[i]:
+            return provided[i][name]
+        dt, M = FIELDS[name]
+        N = provided[i]['N']
+        if i > 0 and provided[0]['N'] == N:
+            return expected(0, name)
+        val = np.empty((N,) if M == 1 else (N, M), dtype=dt)
+        val[...] = defaults[name]
+        return val
+
+    for reader in (lambda: hoomd.open(tmp_gsd, 'r'),
+                   lambda: hoomd.HOOMDTrajectory(pypgsd.PGSDFile(open(tmp_gsd, 'rb')))):
+        with reader() as t:
+            assert len(t) == n_frames
+            for i in list(range(n_frames))[::-1] + [0]:
+                s = t[i]
+                assert s.particles.N == provided[i]['N'], (seed, i)
+                step = provided[i].get('step', provided[0].get('step', 0))
+                assert s.configuration.step == step, (seed, i)
+                box = provided[i].get('box', provided[0].get('box', [1, 1, 1, 0, 0, 0]))
+                np.testing.assert_array_equal(s.configuration.box, np.array(box, dtype=np.float32))
+                for name in FIELDS:
+                    got, exp = getattr(s.particles, name), expected(i, name)
+                    assert got.dtype == exp.dtype and got.shape == exp.shape, (seed, i, name)
+                    np.testing.assert_array_equal(got, exp, err_msg="seed %d frame %d %s" % (seed, i, name))
+                log = provided[i].get('log/e', provided[0].get('log/e'))
+                if log is None:
+                    assert 'e' not in s.log
+                else:
+                    np.testing.assert_array_equal(s.log['e'], log)
