@@ -18,9 +18,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <chrono>
-#include <sys/file.h>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -69,13 +67,6 @@ class DevicePipeline
         // halves the rate on tmpfs (profiles/r01_io_probes.md), so one writer is the default.
         if (m_cfg.n_writers == 0)
             m_cfg.n_writers = 1;
-        if (const char* e = getenv("PGSD_WRITE_LOCK_BURST"))
-            m_lock_burst = atoi(e) > 0 ? atoi(e) : 1;
-        if (const char* e = getenv("PGSD_WRITE_LOCK"))
-            if (atoi(e) == 0)
-                m_lock_burst = 1; // no lock at all: pwrite_locked() honours the same switch
-        if (m_cfg.n_writers != 1)
-            m_lock_burst = 1;
         HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
         m_slabs.resize(m_cfg.n_slabs);
@@ -564,7 +555,6 @@ class DevicePipeline
                     continue;
                     }
                 long long foff = job.file_offset + (long long)off;
-                m_writes_queued.fetch_add(1);
                 writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
                 }
             if (c0 && c1)
@@ -704,31 +694,11 @@ class DevicePipeline
         else
             {
             auto t0 = std::chrono::steady_clock::now();
-            int w;
-            if (m_shared && m_lock_burst > 1)
-                {
-                // Several ranks write one file: keep the advisory lock over a run of pieces that are
-                // already queued, so that ownership of the file's page-cache structures changes
-                // hands less often (one writer thread per rank: see the constructor).
-                if (m_lock_run == 0)
-                    while (flock(m_fd, LOCK_EX) != 0 && errno == EINTR)
-                        {
-                        }
-                w = pwrite_full(m_fd, s.host, n, foff);
-                m_lock_run++;
-                if (m_lock_run >= m_lock_burst || m_writes_queued.load() <= 1)
-                    {
-                    flock(m_fd, LOCK_UN);
-                    m_lock_run = 0;
-                    }
-                }
-            else
-                w = pwrite_locked(m_fd, s.host, n, foff, m_shared);
+            int w = pwrite_locked(m_fd, s.host, n, foff, m_shared);
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (w != 0)
                 fail(std::string("pwrite: ") + strerror(-w), true, -w);
             }
-        m_writes_queued.fetch_sub(1);
         release_slab(si);
         piece_done(n, ms);
         }
@@ -769,9 +739,6 @@ class DevicePipeline
     std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
     size_t m_reads_outstanding = 0;
     std::vector<std::shared_ptr<ReadReq>> m_unpack_pending; // guarded by m_copy_mutex
-    std::atomic<int> m_writes_queued{0};
-    int m_lock_burst = 1; // pieces written per hold of the advisory file lock (single writer thread only)
-    int m_lock_run = 0;   // writer thread only
     std::thread m_dispatcher;
     std::mutex m_mutex;
     std::condition_variable m_cv_jobs, m_cv_slabs, m_cv_done;
