@@ -20,6 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=10_000_000)
 ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--slab-mib", type=int, default=0)
+ap.add_argument("--slabs", type=int, default=0)
 a = ap.parse_args()
 N = a.N
 path = os.path.join(a.dir, "pgsd_read_bench_%d.gsd" % os.getpid())
@@ -34,6 +36,8 @@ for i in range(a.frames):
     f.end_frame()
 f.close()
 r = fl.open(path, 'r')
+if a.slab_mib or a.slabs:
+    r.configure_device(slab_bytes=(a.slab_mib or 16) << 20, n_slabs=a.slabs or 16)
 pos4 = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
 vel4 = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
 times = []
