@@ -229,3 +229,23 @@ def test_async_end_frame_keeps_layout_and_snapshots_values(tmp_path):
     assert lib.oracle_close(h) == 0
     with open(mine, 'rb') as a, open(ref, 'rb') as b:
         assert a.read() == b.read()
+
+
+def test_reading_back_right_after_an_asynchronous_frame(tmp_gsd):
+    """No frame_sync between end_frame(wait=False) and the read: the read itself waits for the
+    bytes that are still on their way (host read and device read)."""
+    import pgsd.fl as fl
+    N = 600_000
+    pos = torch.randn((N, 4), device="cuda")
+    with fl.open(tmp_gsd, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        f.configure_device(slab_bytes=256 * 1024, n_slabs=2)          # a slow, narrow pipeline
+        for i in range(3):
+            f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3)))],
+                           offset=np.array([N]))
+            f.end_frame(wait=False)
+        got = f.read_chunk(2, 'particles/position')
+        assert torch.equal(torch.from_numpy(got), pos[:, :3].cpu())
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3)))], offset=np.array([N]))
+        f.end_frame(wait=False)
+        back = f.read_chunk_device(3, 'particles/position')
+        assert torch.equal(back, pos[:, :3].contiguous())
