@@ -249,3 +249,33 @@ def test_reading_back_right_after_an_asynchronous_frame(tmp_gsd):
         f.end_frame(wait=False)
         back = f.read_chunk_device(3, 'particles/position')
         assert torch.equal(back, pos[:, :3].contiguous())
+
+
+def test_handles_give_back_their_device_and_pinned_memory(tmp_path):
+    """open -> device write -> device read -> close, many times: staging arenas, pinned rings,
+    streams and events are released with the handle."""
+    import resource
+    import pgsd.fl as fl
+    N = 200_000
+    pos = torch.randn((N, 4), device="cuda")
+
+    def cycle(i):
+        path = str(tmp_path / ("h%d.gsd" % (i % 3)))
+        with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+            f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3)))], offset=np.array([N]))
+            f.end_frame()
+        with fl.open(path, 'r') as f:
+            f.read_chunk_device(0, 'particles/position')
+
+    for i in range(3):
+        cycle(i)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for i in range(40):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert free0 - free1 < 64 << 20, (free0, free1)              # one handle holds a 256 MiB arena
+    assert (rss1 - rss0) * 1024 < 256 << 20, (rss0, rss1)        # ... and 256 + 128 MiB of pinned rings
