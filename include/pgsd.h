@@ -411,7 +411,8 @@ extern "C"
 
     /* Device twin of pgsd_read_chunk (reference pgsd.h:604-610) for a row slab: rows
        [row_offset, row_offset + N) of `chunk` (found with pgsd_find_chunk, valid on every rank)
-       are read with pread, streamed to HBM through the pinned slab ring and unpacked by a HIP
+       are read with pread (16 threads, 4 MiB pieces, a pinned ring of their own; PGSD_READERS /
+       PGSD_READ_PIECE_MIB override), streamed to HBM and unpacked by a HIP
        kernel.  Asynchronous: complete after pgsd_device_wait_read(), which also issues the
        unpack of everything read since the last wait as one launch (chunks that together restore
        whole rows of one array -- position.xyz + type id -- are written as whole rows). Every
