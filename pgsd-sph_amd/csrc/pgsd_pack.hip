@@ -1,6 +1,8 @@
 // pgsd_pack.hip -- gfx950 (CDNA4 / MI355X) kernels of the snapshot pack path.
 //
 // pack:    chunk[i][c] = convert(src[(order ? order[i] : i) * stride + col0 + c])
+// unpack:  the inverse for restart reads, all chunks of a frame in one launch, whole destination
+//          rows assembled in registers where the launch restores every column of an array.
 //          for every field of a frame, from HBM-resident particle arrays (HOOMD-style
 //          float4 / double4 / scalar arrays) into dense GSD chunk buffers.
 // select:  stream compaction (filtered snapshots): wave ballot / popcount scans give each
@@ -15,9 +17,10 @@
 //     registers, where bandwidth is ~25x the per-CU share of HBM.
 //   * fields that read the same source array (position.xyz and the type id HOOMD keeps
 //     in position.w) form one group: the tile is fetched from HBM once.
-//   * 64-wide wavefronts, 256-thread workgroups, <= 32 KiB LDS per workgroup so that >= 5
-//     workgroups (20 waves) per CU keep ~100 KiB of loads in flight per CU; the grid is
-//     capped at 8 workgroups per CU x 256 CUs and strides over tiles.
+//   * 64-wide wavefronts, 256-thread workgroups, tiles of 1024 rows: all source arrays of a tile
+//     are staged before ONE barrier (16-40 KiB of LDS per workgroup, bank-skewed image), the
+//     grid is min(tiles, 4 workgroups per CU x 256 CUs, LDS residency) and strides over tiles so
+//     that the resident workgroups stream one contiguous window of every array.
 //   * source tiles are read once and chunk tiles written once: non-temporal hints keep
 //     them from displacing each other in L2.
 //
