@@ -1,10 +1,10 @@
 // pgsd_pack.hip -- gfx950 (CDNA4 / MI355X) kernels of the snapshot pack path.
 //
 // pack:    chunk[i][c] = convert(src[(order ? order[i] : i) * stride + col0 + c])
-// unpack:  the inverse for restart reads, all chunks of a frame in one launch, whole destination
-//          rows assembled in registers where the launch restores every column of an array.
 //          for every field of a frame, from HBM-resident particle arrays (HOOMD-style
 //          float4 / double4 / scalar arrays) into dense GSD chunk buffers.
+// unpack:  the inverse for restart reads, all chunks of a frame in one launch, whole destination
+//          rows assembled in registers where the launch restores every column of an array.
 // select:  stream compaction (filtered snapshots): wave ballot / popcount scans give each
 //          workgroup's count, a one-block scan turns counts into offsets (= per-chunk row
 //          and byte counts), a scatter pass writes the index list.
