@@ -279,3 +279,30 @@ def test_handles_give_back_their_device_and_pinned_memory(tmp_path):
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     assert free0 - free1 < 64 << 20, (free0, free1)              # one handle holds a 256 MiB arena
     assert (rss1 - rss0) * 1024 < 512 << 20, (rss0, rss1)        # ... and 256 + 128 MiB of pinned rings; 40 leaked ones would be 15 GiB
+
+
+@pytest.mark.parametrize("slab_bytes,n_slabs,writers", [(1000, 1, 1), (4096, 2, 3), (12345, 3, 2), (1 << 30, 1, 1)])
+def test_odd_pipeline_geometries_write_the_same_bytes(slab_bytes, n_slabs, writers, tmp_path):
+    """slab sizes that divide nothing, a single slab, more writers than slabs, one giant slab"""
+    import pgsd.fl as fl
+    N = 20_011
+    rng = np.random.default_rng(slab_bytes % 977)
+    pos4 = G.rand_array(rng, (N, 4), np.float32)
+    img = rng.integers(-9, 9, size=(N, 3)).astype(np.int32)
+    paths = []
+    for cfg in (None, (slab_bytes, n_slabs, writers)):
+        path = str(tmp_path / ("g%d.gsd" % len(paths)))
+        with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+            if cfg:
+                f.configure_device(slab_bytes=cfg[0], n_slabs=cfg[1], n_writers=cfg[2])
+            for i in range(2):
+                f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dev(pos4), columns=(0, 3))),
+                                ('particles/image', dev(img))], offset=np.array([N]))
+                f.end_frame()
+        paths.append(path)
+    with open(paths[0], 'rb') as a, open(paths[1], 'rb') as b:
+        assert a.read() == b.read()
+    with fl.open(paths[1], 'r') as f:
+        if slab_bytes < (1 << 20):
+            f.configure_device(slab_bytes=slab_bytes, n_slabs=n_slabs)
+        np.testing.assert_array_equal(f.read_chunk_device(1, 'particles/image').cpu().numpy(), img)
