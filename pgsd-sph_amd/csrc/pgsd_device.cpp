@@ -69,16 +69,38 @@ class DevicePipeline
             m_cfg.n_writers = 1;
         HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
+        // The pinned slabs, the thread that copies them into the page cache and the pages it
+        // allocates there all belong on the NUMA node the GPU hangs off (two-socket hosts: the
+        // other node costs ~10 % of the write rate, profiles/r01_numa.log).
+        char bdf[32] = {0};
+        m_numa = hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), m_cfg.device) == hipSuccess
+                 && numa_cpus_of_pci_device(bdf, &m_numa_cpus);
         m_slabs.resize(m_cfg.n_slabs);
-        for (auto& s : m_slabs)
+        hipError_t alloc_err = hipSuccess;
+        std::thread allocator(
+            [&]
             {
-            HIP_TRY(hipHostMalloc((void**)&s.host, m_cfg.slab_bytes, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-            }
+                // first touch decides the node: allocate from a thread that runs there
+                if (m_numa)
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
+                (void)hipSetDevice(m_cfg.device);
+                for (auto& s : m_slabs)
+                    {
+                    hipError_t e = hipHostMalloc((void**)&s.host, m_cfg.slab_bytes, hipHostMallocDefault);
+                    if (e == hipSuccess)
+                        e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+                    if (e != hipSuccess && alloc_err == hipSuccess)
+                        alloc_err = e;
+                    }
+            });
+        allocator.join();
+        HIP_TRY(alloc_err);
         for (uint32_t i = 0; i < m_cfg.n_slabs; i++)
             m_free_slabs.push_back(i);
-        m_pool = writer_pool_create(m_cfg.n_writers);
+        m_pool = writer_pool_create(m_cfg.n_writers, m_numa ? &m_numa_cpus : nullptr);
         m_dispatcher = std::thread([this] { dispatch_loop(); });
+        if (m_numa)
+            (void)pthread_setaffinity_np(m_dispatcher.native_handle(), sizeof(cpu_set_t), &m_numa_cpus);
         m_ok = true;
         return PGSD_SUCCESS;
         }
@@ -243,17 +265,30 @@ class DevicePipeline
             if (const char* e = getenv("PGSD_READ_PIECE_MIB"))
                 m_read_piece = (size_t)(atoi(e) > 0 ? atoi(e) : 4) << 20;
             m_rslabs.resize((size_t)n * 2);
-            for (auto& s : m_rslabs)
+            hipError_t alloc_err = hipSuccess;
+            std::thread allocator(
+                [&]
                 {
-                HIP_TRY(hipHostMalloc((void**)&s.host, m_read_piece, hipHostMallocDefault));
-                HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-                }
+                    if (m_numa) // first touch on the GPU's node, like the write ring
+                        (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
+                    (void)hipSetDevice(m_cfg.device);
+                    for (auto& s : m_rslabs)
+                        {
+                        hipError_t e = hipHostMalloc((void**)&s.host, m_read_piece, hipHostMallocDefault);
+                        if (e == hipSuccess)
+                            e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+                        if (e != hipSuccess && alloc_err == hipSuccess)
+                            alloc_err = e;
+                        }
+                });
+            allocator.join();
+            HIP_TRY(alloc_err);
                 {
                 std::lock_guard<std::mutex> g(m_mutex);
                 for (uint32_t i = 0; i < m_rslabs.size(); i++)
                     m_free_rslabs.push_back(i);
                 }
-            m_read_pool = writer_pool_create(n);
+            m_read_pool = writer_pool_create(n, m_numa ? &m_numa_cpus : nullptr);
             }
         auto req = std::make_shared<ReadReq>();
         req->job = job;
@@ -792,6 +827,8 @@ class DevicePipeline
     bool m_stop = false;
     std::string m_error;
     bool m_io_error = false;
+    bool m_numa = false;    // m_numa_cpus = CPUs of the GPU's NUMA node (two-socket hosts)
+    cpu_set_t m_numa_cpus;
     int m_io_errno = 0; // errno of the failed write (worker thread), handed to the caller's thread
     pgsd_device_stats m_stats = {};
     };

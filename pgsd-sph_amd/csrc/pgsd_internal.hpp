@@ -5,6 +5,7 @@
 #include "pgsd.h"
 
 #include <cstdint>
+#include <sched.h>
 #include <functional>
 #include <string>
 #include <vector>
@@ -31,7 +32,8 @@ inline int comm_barrier(const pgsd_comm& c)
 
 // ---- host IO: a pool of pwrite threads shared by the host and the device path ----
 class WriterPool;
-WriterPool* writer_pool_create(unsigned n_threads);
+WriterPool* writer_pool_create(unsigned n_threads, const cpu_set_t* cpus = nullptr);
+bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out);
 void writer_pool_destroy(WriterPool*);
 void writer_pool_submit(WriterPool*, std::function<void()> fn);
 // Write [buf, buf+bytes) at `offset` of fd, split over the pool; blocks until done.

@@ -7,7 +7,12 @@
 // exclusive lock and scale with threads.
 #include "pgsd_internal.hpp"
 
+#include <cctype>
 #include <cerrno>
+#include <cstdio>
+#include <pthread.h>
+#include <sched.h>
+#include <string>
 #include <cstdlib>
 #include <sys/file.h>
 #include <condition_variable>
@@ -83,12 +88,16 @@ void pread_some(int fd, void* buf, size_t bytes, long long offset)
 class WriterPool
     {
     public:
-    explicit WriterPool(unsigned n) : m_stop(false)
+    explicit WriterPool(unsigned n, const cpu_set_t* cpus = nullptr) : m_stop(false)
         {
         if (n == 0)
             n = 1;
         for (unsigned i = 0; i < n; i++)
+            {
             m_threads.emplace_back([this] { run(); });
+            if (cpus) // keep the copy loops next to the memory they touch
+                (void)pthread_setaffinity_np(m_threads.back().native_handle(), sizeof(cpu_set_t), cpus);
+            }
         }
 
     ~WriterPool()
@@ -141,9 +150,66 @@ class WriterPool
     bool m_stop;
     };
 
-WriterPool* writer_pool_create(unsigned n_threads)
+WriterPool* writer_pool_create(unsigned n_threads, const cpu_set_t* cpus)
     {
-    return new WriterPool(n_threads);
+    return new WriterPool(n_threads, cpus);
+    }
+
+// CPUs of the NUMA node a PCI device hangs off, intersected with what this process may run on.
+// false when the node is unknown (-1), the machine has one node, or PGSD_NUMA=0.
+bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out)
+    {
+    if (const char* e = getenv("PGSD_NUMA"))
+        if (atoi(e) == 0)
+            return false;
+    char path[256], buf[4096];
+    std::string bdf(pci_bus_id);
+    for (char& c : bdf)
+        c = (char)tolower((unsigned char)c);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf.c_str());
+    FILE* f = fopen(path, "r");
+    if (!f)
+        return false;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1)
+        node = -1;
+    fclose(f);
+    if (node < 0)
+        return false;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f)
+        return false;
+    size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+        return false;
+    CPU_ZERO(out);
+    int count = 0;
+    for (char* p = buf; *p;)
+        {
+        char* end;
+        long a = strtol(p, &end, 10);
+        if (end == p)
+            break;
+        long b = a;
+        if (*end == '-')
+            b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, &allowed))
+                {
+                CPU_SET((int)c, out);
+                count++;
+                }
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',' )
+            break;
+        }
+    int total = CPU_COUNT(&allowed);
+    return count > 0 && count < total; // a single node (or all CPUs) needs no pinning
     }
 
 void writer_pool_destroy(WriterPool* p)
