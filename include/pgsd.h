@@ -355,7 +355,9 @@ extern "C"
        records an event on the caller's *source stream* -- the stream on which the kernels that
        produce the particle arrays were enqueued (hipStream_t as void*; NULL = the null stream,
        which is also PyTorch's default stream) -- and makes the pack stream wait for it, so
-       arrays still being written by earlier asynchronous work are packed only when complete. */
+       arrays still being written by earlier asynchronous work are packed only when complete.
+       The unpack of pgsd_device_wait_read() waits for the same stream before it writes the
+       destination arrays. */
     int pgsd_device_set_source_stream(struct pgsd_handle* handle, void* stream);
 
     struct pgsd_device_stats

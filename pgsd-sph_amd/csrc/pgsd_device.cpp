@@ -689,6 +689,22 @@ class DevicePipeline
                 if (e == hipSuccess)
                     e = hipStreamWaitEvent(m_pack_stream, r->all_copied, 0);
                 }
+            // The destinations belong to the caller: whatever its stream still has in flight on them
+            // (a caching allocator hands out blocks whose previous owner may not have finished) comes
+            // first, exactly as the pack waits for the producers of its sources.
+            hipEvent_t ready = nullptr;
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+            if (e == hipSuccess)
+                {
+                    {
+                    std::lock_guard<std::mutex> g(m_mutex);
+                    m_misc_events.push_back(ready);
+                    }
+                e = hipEventRecord(ready, m_source_stream);
+                }
+            if (e == hipSuccess)
+                e = hipStreamWaitEvent(m_pack_stream, ready, 0);
             std::string err;
             if (e != hipSuccess)
                 fail(std::string("read pipeline event: ") + hipGetErrorString(e));

@@ -554,6 +554,8 @@ class PGSDFile(object):
         dst.dst_col0 = c0
         dst.bitcast = 1 if bitcast else 0
         self.__keepalive.append((out, order))
+        if not self.__explicit_stream:
+            self._sync_source_stream()      # the unpack is ordered behind this stream's use of `out`
         retval = lib.pgsd_read_chunk_device(self._h(), e, int(N), int(offset), ctypes.byref(dst))
         _raise_on_error(retval, self.__name)
         if wait:
