@@ -127,7 +127,7 @@ def test_fused_device_write_matches_oracle(N, tmp_path):
     g.close()
 
 
-def _rank_main(rank, P, shm, path, counts, seed, q):
+def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False):
     try:
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -150,7 +150,7 @@ def _rank_main(rank, P, shm, path, counts, seed, q):
             f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
                             ('particles/typeid', fl.DeviceField.from_tensor(dtid, out_dtype=np.uint32))],
                            offset=np.array(counts), rank=rank)
-            f.end_frame()
+            f.end_frame(wait=not async_seal)
         f.close()
         _lib.lib.pgsd_comm_finalize()
         q.put((rank, "ok"))
@@ -160,8 +160,9 @@ def _rank_main(rank, P, shm, path, counts, seed, q):
         raise
 
 
+@pytest.mark.parametrize("async_seal", [False, True])
 @pytest.mark.parametrize("counts", [[600, 401], [0, 333, 1]])
-def test_multi_rank_device_write_matches_oracle(counts, tmp_path):
+def test_multi_rank_device_write_matches_oracle(counts, async_seal, tmp_path):
     """P processes share cuda:0 (<= 3 ranks), talk through the shm communicator, each packs
     and writes its own partition; the file equals the oracle's P-rank file."""
     P = len(counts)
@@ -170,7 +171,7 @@ def test_multi_rank_device_write_matches_oracle(counts, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     shm = "pgsdgpu_%s" % uuid.uuid4().hex[:10]
-    procs = [ctx.Process(target=_rank_main, args=(r, P, shm, mine, counts, seed, q)) for r in range(P)]
+    procs = [ctx.Process(target=_rank_main, args=(r, P, shm, mine, counts, seed, q, async_seal)) for r in range(P)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
