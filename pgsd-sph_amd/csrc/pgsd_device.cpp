@@ -42,6 +42,138 @@ namespace pgsd_amd
             }                                                                              \
         } while (0)
 
+// Reader threads and their pinned ring are shared by every handle that reads on a device: ten
+// trajectories open for reading cost 16 threads and 128 MiB of pinned memory, not 160 and 1.3 GiB.
+// Created by the first reading pipeline, destroyed with the last.
+struct ReadEngine
+    {
+    struct Slab
+        {
+        char* host = nullptr;
+        hipEvent_t copied = nullptr;
+        };
+    int device = 0;
+    int refs = 0;
+    size_t piece = (size_t)4 << 20;
+    WriterPool* pool = nullptr;
+    std::vector<Slab> slabs;
+    std::deque<uint32_t> free_slabs;
+    std::mutex m;
+    std::condition_variable cv;
+
+    int get_slab()
+        {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !free_slabs.empty(); });
+        int si = (int)free_slabs.front();
+        free_slabs.pop_front();
+        return si;
+        }
+
+    void put_slab(int si)
+        {
+            {
+            std::lock_guard<std::mutex> g(m);
+            free_slabs.push_back((uint32_t)si);
+            }
+        cv.notify_one();
+        }
+
+    static std::mutex& registry_mutex()
+        {
+        static std::mutex mu;
+        return mu;
+        }
+
+    static std::vector<ReadEngine*>& registry()
+        {
+        static std::vector<ReadEngine*> r;
+        return r;
+        }
+
+    static ReadEngine* acquire(int device, const cpu_set_t* cpus, hipError_t* err)
+        {
+        std::lock_guard<std::mutex> g(registry_mutex());
+        for (ReadEngine* e : registry())
+            if (e->device == device)
+                {
+                e->refs++;
+                return e;
+                }
+        ReadEngine* e = new ReadEngine;
+        e->device = device;
+        // Reads of the page cache take no exclusive lock and scale with threads; pieces smaller
+        // than the write slabs keep all of them busy on one chunk and start the H2D copies
+        // earlier (profiles/r01_read_sweep.log: 16 readers x 4 MiB pieces beat 8 x 16 MiB by 20-40 %).
+        unsigned n = 16;
+        if (const char* v = getenv("PGSD_READERS"))
+            n = (unsigned)atoi(v) > 0 ? (unsigned)atoi(v) : n;
+        if (const char* v = getenv("PGSD_READ_PIECE_MIB"))
+            e->piece = (size_t)(atoi(v) > 0 ? atoi(v) : 4) << 20;
+        e->slabs.resize((size_t)n * 2);
+        hipError_t alloc_err = hipSuccess;
+        std::thread allocator(
+            [&]
+            {
+                if (cpus) // first touch on the GPU's node, like the write ring
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), cpus);
+                (void)hipSetDevice(device);
+                for (auto& s : e->slabs)
+                    {
+                    hipError_t rc = hipHostMalloc((void**)&s.host, e->piece, hipHostMallocDefault);
+                    if (rc == hipSuccess)
+                        rc = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+                    if (rc != hipSuccess && alloc_err == hipSuccess)
+                        alloc_err = rc;
+                    }
+            });
+        allocator.join();
+        if (alloc_err != hipSuccess)
+            {
+            e->free_all();
+            delete e;
+            *err = alloc_err;
+            return nullptr;
+            }
+        for (uint32_t i = 0; i < e->slabs.size(); i++)
+            e->free_slabs.push_back(i);
+        e->pool = writer_pool_create(n, cpus);
+        e->refs = 1;
+        registry().push_back(e);
+        return e;
+        }
+
+    static void release(ReadEngine* e)
+        {
+            {
+            std::lock_guard<std::mutex> g(registry_mutex());
+            if (--e->refs > 0)
+                return;
+            auto& r = registry();
+            for (size_t i = 0; i < r.size(); i++)
+                if (r[i] == e)
+                    r.erase(r.begin() + (long)i);
+            }
+        if (e->pool)
+            writer_pool_destroy(e->pool); // joins the readers (no pipeline has work queued any more)
+        (void)hipSetDevice(e->device);
+        e->free_all();
+        delete e;
+        }
+
+    void free_all()
+        {
+        for (auto& s : slabs)
+            {
+            if (s.copied)
+                (void)hipEventDestroy(s.copied);
+            if (s.host)
+                (void)hipHostFree(s.host);
+            }
+        slabs.clear();
+        }
+    };
+
 class DevicePipeline
     {
     public:
@@ -117,20 +249,20 @@ class DevicePipeline
             m_cv_slabs.notify_all();
             m_dispatcher.join();
             }
-        if (m_read_pool)
-            writer_pool_destroy(m_read_pool);
+        if (m_reader)
+            {
+                {
+                // the readers are shared: wait for this handle's pieces instead of joining them
+                std::unique_lock<std::mutex> lk(m_mutex);
+                m_cv_done.wait(lk, [this] { return m_reads_outstanding == 0; });
+                }
+            ReadEngine::release(m_reader);
+            }
         if (m_pool)
             writer_pool_destroy(m_pool); // joins the writers
         (void)hipSetDevice(m_cfg.device);
         release_events();
         for (auto& s : m_slabs)
-            {
-            if (s.copied)
-                (void)hipEventDestroy(s.copied);
-            if (s.host)
-                (void)hipHostFree(s.host);
-            }
-        for (auto& s : m_rslabs)
             {
             if (s.copied)
                 (void)hipEventDestroy(s.copied);
@@ -253,59 +385,30 @@ class DevicePipeline
         if (rc != PGSD_SUCCESS)
             return rc;
         job.src = stage;
-        if (!m_read_pool)
+        if (!m_reader)
             {
-            // Reads of the page cache take no exclusive lock and scale with threads; pieces smaller
-            // than the write slabs keep all of them busy on one chunk and start the H2D copies
-            // earlier (profiles/r01_read_sweep.log: 16 readers x 4 MiB pieces beat 8 x 16 MiB by 20-40 %).
-            unsigned n = 16;
-            if (const char* e = getenv("PGSD_READERS"))
-                n = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : n;
-            m_read_piece = (size_t)4 << 20;
-            if (const char* e = getenv("PGSD_READ_PIECE_MIB"))
-                m_read_piece = (size_t)(atoi(e) > 0 ? atoi(e) : 4) << 20;
-            m_rslabs.resize((size_t)n * 2);
-            hipError_t alloc_err = hipSuccess;
-            std::thread allocator(
-                [&]
-                {
-                    if (m_numa) // first touch on the GPU's node, like the write ring
-                        (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
-                    (void)hipSetDevice(m_cfg.device);
-                    for (auto& s : m_rslabs)
-                        {
-                        hipError_t e = hipHostMalloc((void**)&s.host, m_read_piece, hipHostMallocDefault);
-                        if (e == hipSuccess)
-                            e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
-                        if (e != hipSuccess && alloc_err == hipSuccess)
-                            alloc_err = e;
-                        }
-                });
-            allocator.join();
-            HIP_TRY(alloc_err);
-                {
-                std::lock_guard<std::mutex> g(m_mutex);
-                for (uint32_t i = 0; i < m_rslabs.size(); i++)
-                    m_free_rslabs.push_back(i);
-                }
-            m_read_pool = writer_pool_create(n, m_numa ? &m_numa_cpus : nullptr);
+            hipError_t rerr = hipSuccess;
+            m_reader = ReadEngine::acquire(m_cfg.device, m_numa ? &m_numa_cpus : nullptr, &rerr);
+            if (!m_reader)
+                HIP_TRY(rerr);
             }
+        const size_t piece = m_reader->piece;
         auto req = std::make_shared<ReadReq>();
         req->job = job;
         req->N = N;
-        req->pieces_left = (bytes + m_read_piece - 1) / m_read_piece;
+        req->pieces_left = (bytes + piece - 1) / piece;
         HIP_TRY(hipEventCreateWithFlags(&req->all_copied, hipEventDisableTiming));
             {
             std::lock_guard<std::mutex> g(m_mutex);
             m_misc_events.push_back(req->all_copied);
-            m_reads_outstanding++;
+            m_reads_outstanding += req->pieces_left; // counted per piece: see read_piece()
             }
-        for (size_t off = 0; off < bytes; off += m_read_piece)
+        for (size_t off = 0; off < bytes; off += piece)
             {
-            size_t n = std::min(m_read_piece, bytes - off);
+            size_t n = std::min(piece, bytes - off);
             char* dst = (char*)stage + off;
             long long foff = file_offset + (long long)off;
-            writer_pool_submit(m_read_pool, [this, req, dst, n, foff] { read_piece(req, dst, n, foff); });
+            writer_pool_submit(m_reader->pool, [this, req, dst, n, foff] { read_piece(req, dst, n, foff); });
             }
         return PGSD_SUCCESS;
         }
@@ -635,26 +738,6 @@ class DevicePipeline
         return si;
         }
 
-    int acquire_rslab()
-        {
-        std::unique_lock<std::mutex> lk(m_mutex);
-        m_cv_slabs.wait(lk, [this] { return m_stop || !m_free_rslabs.empty() || !m_error.empty(); });
-        if (m_free_rslabs.empty() || !m_error.empty())
-            return -1;
-        int si = (int)m_free_rslabs.front();
-        m_free_rslabs.pop_front();
-        return si;
-        }
-
-    void release_rslab(int si)
-        {
-            {
-            std::lock_guard<std::mutex> g(m_mutex);
-            m_free_rslabs.push_back((uint32_t)si);
-            }
-        m_cv_slabs.notify_all();
-        }
-
     void read_done()
         {
         std::lock_guard<std::mutex> g(m_mutex);
@@ -717,12 +800,13 @@ class DevicePipeline
     void read_piece(std::shared_ptr<ReadReq> req, char* dst, size_t n, long long foff)
         {
         (void)hipSetDevice(m_cfg.device);
-        int si = failed() ? -1 : acquire_rslab();
+        ReadEngine* const reader = m_reader; // the engine may outlive this pipeline, not the other way round
+        int si = failed() ? -1 : reader->get_slab();
         bool last = false;
         bool ok = si >= 0;
         if (ok)
             {
-            Slab& s = m_rslabs[(size_t)si];
+            ReadEngine::Slab& s = reader->slabs[(size_t)si];
             // pread in one go; a short read means the file is shorter than its index claims
             size_t got = 0;
             while (got < n)
@@ -744,7 +828,7 @@ class DevicePipeline
             std::lock_guard<std::mutex> g(m_copy_mutex);
             if (ok)
                 {
-                Slab& s = m_rslabs[(size_t)si];
+                ReadEngine::Slab& s = reader->slabs[(size_t)si];
                 hipError_t e = hipMemcpyAsync(dst, s.host, n, hipMemcpyHostToDevice, m_copy_stream);
                 if (e == hipSuccess)
                     e = hipEventRecord(s.copied, m_copy_stream);
@@ -770,11 +854,13 @@ class DevicePipeline
         if (si >= 0)
             {
             if (ok)
-                (void)hipEventSynchronize(m_rslabs[(size_t)si].copied);
-            release_rslab(si);
+                (void)hipEventSynchronize(reader->slabs[(size_t)si].copied);
+            reader->put_slab(si);
             }
-        if (last)
-            read_done();
+        (void)last;
+        // Last touch of the pipeline by this piece: the destructor (and wait_read) wait for the count
+        // of PIECES to reach zero, so no straggler of a finished chunk is left behind.
+        read_done();
         }
 
     void write_piece(int si, size_t n, long long foff)
@@ -829,12 +915,9 @@ class DevicePipeline
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pack_events, m_copy_events;
     std::vector<hipEvent_t> m_misc_events;
     WriterPool* m_pool = nullptr;
-    WriterPool* m_read_pool = nullptr;
+    ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device
     std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
     size_t m_reads_outstanding = 0;
-    std::vector<Slab> m_rslabs;         // pinned ring of the read path (smaller pieces than the write ring)
-    std::deque<uint32_t> m_free_rslabs; // guarded by m_mutex
-    size_t m_read_piece = (size_t)4 << 20;
     std::vector<std::shared_ptr<ReadReq>> m_unpack_pending; // guarded by m_copy_mutex
     std::thread m_dispatcher;
     std::mutex m_mutex;

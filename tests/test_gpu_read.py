@@ -272,3 +272,43 @@ def test_hoomd_read_frame_device_round_trip(tmp_gsd):
         part = t.read_frame_device(0, part=(100, 777))
         assert part.particles.N == 777
         assert torch.equal(part.particles.velocity, vel4[100:877, :3].contiguous())
+
+
+def test_many_reading_handles_share_one_reader_engine(tmp_path):
+    """Six trajectories open for reading at once: their pieces go through ONE set of reader threads
+    and one pinned ring; handles are closed while others still have reads in flight."""
+    import threading
+    import pgsd.fl as fl
+    import pgsd.pypgsd as pypgsd
+    N = 150_001
+    paths, handles = [], []
+    for k in range(6):
+        p = str(tmp_path / ("t%d.gsd" % k))
+        _write_file(p, N + k, frames=1)
+        paths.append(p)
+    before = threading.active_count()
+    handles = [fl.open(p, 'r') for p in paths]
+    outs = []
+    for k, f in enumerate(handles):
+        outs.append((f.read_chunk_device(0, 'particles/position', wait=False),
+                     f.read_chunk_device(0, 'particles/image', wait=False)))
+    import os
+    n_threads = len(os.listdir('/proc/self/task'))
+    for k in (5, 0, 3):
+        handles[k].wait_read()
+        handles[k].close()
+    for k in (1, 2, 4):
+        handles[k].wait_read()
+    for k in range(6):
+        ref = pypgsd.PGSDFile(open(paths[k], 'rb'))
+        assert outs[k][0].cpu().numpy().tobytes() == ref.read_chunk(0, 'particles/position').tobytes(), k
+        assert outs[k][1].cpu().numpy().tobytes() == ref.read_chunk(0, 'particles/image').tobytes(), k
+        ref.close()
+    for k in (1, 2, 4):
+        handles[k].close()
+    # 6 handles x (dispatcher + writer) + 16 shared readers, not 6 x 16 readers
+    assert n_threads < 6 * 16, n_threads
+    # a fresh handle after every reader was released builds a new engine
+    with fl.open(paths[0], 'r') as f:
+        got = f.read_chunk_device(0, 'particles/typeid')
+        assert got.shape[0] == N
