@@ -344,6 +344,7 @@ class DevicePipeline
             m_stats.pack_bytes_out += bytes_out;
             }
 
+        bool ramped = false;
         for (auto& c : chunks)
             {
             size_t bytes = (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type));
@@ -360,12 +361,15 @@ class DevicePipeline
                 j.bytes = bytes;
                 j.file_offset = c.file_offset;
                 j.packed = packed;
-                size_t pieces = (bytes + m_cfg.slab_bytes - 1) / m_cfg.slab_bytes;
-                    {
-                    std::lock_guard<std::mutex> g(m_mutex);
-                    m_outstanding += pieces;
-                    m_jobs.push_back(j);
-                    }
+                j.ramp = !ramped; // the first chunk of a submit starts with small pieces
+                ramped = true;
+                size_t pieces = 0;
+                for (size_t off = 0; off < bytes; off += piece_len(off, bytes, j.ramp))
+                    pieces++;
+                std::unique_lock<std::mutex> lk(m_mutex);
+                m_outstanding += pieces;
+                m_jobs.push_back(j);
+                lk.unlock();
                 m_cv_jobs.notify_one();
                 }
             }
@@ -534,7 +538,21 @@ class DevicePipeline
         size_t bytes;
         long long file_offset;
         hipEvent_t packed;
+        bool ramp;
         };
+
+    // Bytes of the piece that starts at `off`.  The writer cannot start before the first piece has
+    // crossed PCIe, so the first chunk of a frame begins with a 1 MiB and a 4 MiB piece (0.02 ms
+    // instead of 0.3 ms until the first pwrite: 5 % of a 1 M-particle frame) before full slabs follow.
+    size_t piece_len(size_t off, size_t bytes, bool ramp) const
+        {
+        size_t cap = (size_t)m_cfg.slab_bytes;
+        if (ramp && off == 0)
+            cap = std::min(cap, (size_t)1 << 20);
+        else if (ramp && off < ((size_t)5 << 20))
+            cap = std::min(cap, (size_t)4 << 20);
+        return std::min(cap, bytes - off);
+        }
 
     void fail(const std::string& msg, bool io = false, int io_errno = 0)
         {
@@ -678,9 +696,9 @@ class DevicePipeline
                 if (hipEventCreate(&c0) == hipSuccess && hipEventCreate(&c1) == hipSuccess)
                     (void)hipEventRecord(c0, m_copy_stream);
                 }
-            for (size_t off = 0; off < job.bytes; off += m_cfg.slab_bytes)
+            for (size_t off = 0, n = 0; off < job.bytes; off += n)
                 {
-                size_t n = std::min((size_t)m_cfg.slab_bytes, job.bytes - off);
+                n = piece_len(off, job.bytes, job.ramp);
                 if (bad || failed())
                     {
                     bad = true;
