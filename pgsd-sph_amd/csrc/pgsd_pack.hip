@@ -847,7 +847,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scatter_kernel(const uint8
                                                                      const uint64_t* block_offsets,
                                                                      uint32_t* out_index)
     {
+    // The kept rows of this block are compacted in LDS first (each lane drops its <= 16 indices at
+    // its block-local rank), then the block writes them out as one dense, coalesced run: lane i
+    // stores element i of the run instead of 16 scattered stores per lane.
     __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    __shared__ uint32_t local[SEL_PER_BLOCK];
     uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
     uint32_t mask = 0;
     uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
@@ -855,16 +859,36 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scatter_kernel(const uint8
     if ((threadIdx.x & 63) == 63)
         wave_sums[threadIdx.x >> 6] = inc;
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-        wave_off += wave_sums[w];
-    uint64_t pos = block_offsets[blockIdx.x] + wave_off + inc - c;
+    uint32_t wave_off = 0, total = 0;
+    for (uint32_t w = 0; w < SEL_THREADS / 64; w++)
+        {
+        if (w < (threadIdx.x >> 6))
+            wave_off += wave_sums[w];
+        total += wave_sums[w];
+        }
+    uint32_t pos = wave_off + inc - c;
     while (mask)
         {
         int k = __ffs((int)mask) - 1;
         mask &= mask - 1;
-        out_index[pos++] = (uint32_t)(base + (uint64_t)k);
+        local[pos++] = (uint32_t)(base + (uint64_t)k);
         }
+    __syncthreads();
+    uint32_t* out = out_index + block_offsets[blockIdx.x];
+    // 16-byte stores where the run's start allows, 4-byte stores for the ragged ends
+    const uint32_t lead = (uint32_t)((4u - (((uintptr_t)out >> 2) & 3u)) & 3u);
+    const uint32_t head = lead < total ? lead : total;
+    if (threadIdx.x < head)
+        out[threadIdx.x] = local[threadIdx.x];
+    const uint32_t nvec = (total - head) >> 2;
+    for (uint32_t v = threadIdx.x; v < nvec; v += SEL_THREADS)
+        {
+        const uint32_t e = head + 4 * v;
+        u32x4 q = {local[e], local[e + 1], local[e + 2], local[e + 3]};
+        *(u32x4*)(out + e) = q;
+        }
+    for (uint32_t e = head + 4 * nvec + threadIdx.x; e < total; e += SEL_THREADS)
+        out[e] = local[e];
     }
 
 // ------------------------------------------------------------------ host side
