@@ -322,7 +322,7 @@ def main():
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }
     if world == 1 and not args.no_cpu_baseline and args.schema == "pvi":
-        out["cpu_baseline"] = cpu_baseline_reference(N, 32, args.dir) or cpu_baseline(N, 8, args.dir)
+        out["cpu_baseline"] = cpu_baseline_reference(N, 64, args.dir) or cpu_baseline(N, 8, args.dir)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
