@@ -216,18 +216,19 @@ class DevicePipeline
                 if (m_numa)
                     (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
                 (void)hipSetDevice(m_cfg.device);
-                for (auto& s : m_slabs)
+                // two slabs now; the dispatcher (pinned to the same node) adds the rest of the ring
+                // when a frame actually needs them, so a small file never pins 256 MiB
+                for (uint32_t i = 0; i < m_cfg.n_slabs && i < 2; i++)
                     {
-                    hipError_t e = hipHostMalloc((void**)&s.host, m_cfg.slab_bytes, hipHostMallocDefault);
-                    if (e == hipSuccess)
-                        e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+                    hipError_t e = alloc_slab(m_slabs[i]);
                     if (e != hipSuccess && alloc_err == hipSuccess)
                         alloc_err = e;
                     }
             });
         allocator.join();
         HIP_TRY(alloc_err);
-        for (uint32_t i = 0; i < m_cfg.n_slabs; i++)
+        m_slabs_ready = std::min<uint32_t>(m_cfg.n_slabs, 2);
+        for (uint32_t i = 0; i < m_slabs_ready; i++)
             m_free_slabs.push_back(i);
         m_pool = writer_pool_create(m_cfg.n_writers, m_numa ? &m_numa_cpus : nullptr);
         m_dispatcher = std::thread([this] { dispatch_loop(); });
@@ -554,6 +555,14 @@ class DevicePipeline
         return std::min(cap, bytes - off);
         }
 
+    hipError_t alloc_slab(Slab& s)
+        {
+        hipError_t e = hipHostMalloc((void**)&s.host, m_cfg.slab_bytes, hipHostMallocDefault);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+        return e;
+        }
+
     void fail(const std::string& msg, bool io = false, int io_errno = 0)
         {
         std::lock_guard<std::mutex> g(m_mutex);
@@ -706,14 +715,28 @@ class DevicePipeline
                     continue;
                     }
                 int si = -1;
+                bool grow = false;
                     {
                     std::unique_lock<std::mutex> lk(m_mutex);
-                    m_cv_slabs.wait(lk, [this] { return m_stop || !m_free_slabs.empty() || !m_error.empty(); });
-                    if (!m_free_slabs.empty() && m_error.empty())
+                    grow = m_free_slabs.empty() && m_slabs_ready < m_cfg.n_slabs && m_error.empty();
+                    if (!grow)
                         {
-                        si = (int)m_free_slabs.front();
-                        m_free_slabs.pop_front();
+                        m_cv_slabs.wait(lk, [this] { return m_stop || !m_free_slabs.empty() || !m_error.empty(); });
+                        if (!m_free_slabs.empty() && m_error.empty())
+                            {
+                            si = (int)m_free_slabs.front();
+                            m_free_slabs.pop_front();
+                            }
                         }
+                    }
+                if (grow)
+                    {
+                    // only this thread grows the ring; the slot exists already (the vector is full-sized)
+                    hipError_t ge = alloc_slab(m_slabs[m_slabs_ready]);
+                    if (ge == hipSuccess)
+                        si = (int)m_slabs_ready++;
+                    else
+                        fail(std::string("hipHostMalloc (pinned slab): ") + hipGetErrorString(ge));
                     }
                 if (si < 0)
                     {
@@ -927,6 +950,7 @@ class DevicePipeline
     hipStream_t m_pack_stream = nullptr, m_copy_stream = nullptr;
     hipStream_t m_source_stream = nullptr; // null stream unless the caller names another
     std::vector<Slab> m_slabs;
+    uint32_t m_slabs_ready = 0; // slabs allocated so far (grown by the dispatcher thread only)
     std::deque<uint32_t> m_free_slabs;
     std::vector<Arena> m_arenas;
     std::deque<CopyJob> m_jobs;
