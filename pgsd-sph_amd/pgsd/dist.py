@@ -31,15 +31,18 @@ def init_shm(name, rank, size):
         raise RuntimeError("pgsd_comm_init_shm failed: " + _lib.last_error())
 
 
-def init_from_torch(group=None, device=None, prefer_rccl=True):
-    """Use an initialised ``torch.distributed`` group. Returns the back end name."""
+def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=False):
+    """Use an initialised ``torch.distributed`` group. Returns the back end name.
+
+    ``_single_rank_too`` (tests): build the communicator even for a group of one rank, which
+    otherwise gets the trivial "self" communicator."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
         init_self()
         return "self"
     rank, size = dist.get_rank(group), dist.get_world_size(group)
-    if size == 1:
+    if size == 1 and not _single_rank_too:
         init_self()
         return "self"
     backend = dist.get_backend(group)

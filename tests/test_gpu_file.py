@@ -358,3 +358,38 @@ def test_two_trajectories_written_concurrently_from_two_threads(tmp_path):
         _oracle_frames(ref, 1, frames)
         with open(mine, 'rb') as a, open(ref, 'rb') as b:
             assert a.read() == b.read(), tag
+
+
+RCCL_FROM_TORCH = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29%%03d" %% (os.getpid() %% 1000))
+torch.cuda.set_device(0)
+dist.init_process_group(backend=sys.argv[1], rank=0, world_size=1,
+                        **({"device_id": torch.device("cuda", 0)} if sys.argv[1] == "nccl" else {}))
+import pgsd.dist as pdist
+name = pdist.init_from_torch(device=0, _single_rank_too=True)
+counts, row0, n = pdist.partition_rows(12345)
+print(name, [int(c) for c in counts], row0, n)
+pdist.finalize()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("backend,expect", [("nccl", "rccl"), ("gloo", "torch-gloo")])
+def test_communicator_from_a_torch_process_group(backend, expect):
+    """pgsd.dist.init_from_torch end to end in a one-rank group: the unique id travels through a
+    torch broadcast, the library builds its own RCCL communicator next to PyTorch's, the self-check
+    exchange and the cross-rank agreement run, and the row-count allgather works through it (the
+    multi-rank case needs more GPUs than the test box has)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", RCCL_FROM_TORCH % os.path.join(root, "pgsd-sph_amd"), backend],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.strip().splitlines()[-1] == "%s [12345] 0 12345" % expect, p.stdout
