@@ -276,3 +276,36 @@ def test_full_size_pack_matches_independent_gpu_slicing(prefetch, monkeypatch):
     G.hip_pack([(again, np.float32, 3, o_pos, 0, None, False)], N)
     assert torch.equal(again.view(torch.int32), o_pos.view(torch.int32))
     assert int(o_tid.to(torch.int64).sum().item()) == N * (N - 1) // 2
+
+
+def test_arrays_larger_than_4_GiB():
+    """300 M float4 rows (4.8 GB source, 3.6 GB chunk): byte offsets past 2^32 in the pack and in
+    the unpack; checked against torch's own slicing on the GPU."""
+    N = 300_000_000
+    src = torch.empty((N, 4), dtype=torch.float32, device="cuda")
+    src.view(torch.int32).copy_(torch.arange(4 * N, dtype=torch.int32, device="cuda").view(N, 4))  # every word distinct
+    out = torch.empty((N, 3), dtype=torch.float32, device="cuda")
+    w = torch.empty((N,), dtype=torch.int32, device="cuda")
+    G.hip_pack([(out, np.float32, 3, src, 0, None, False), (w, np.uint32, 1, src, 3, None, True)], N)
+    for lo in (0, 89_478_480, 178_956_960, 268_435_440, N - 5000):           # around the 2^30-row / 2^32-byte lines
+        hi = lo + 5000
+        assert torch.equal(out[lo:hi].view(torch.int32), src[lo:hi, :3].contiguous().view(torch.int32)), lo
+        assert torch.equal(w[lo:hi], src[lo:hi, 3].view(torch.int32)), lo
+    assert torch.equal(out.view(torch.int32)[:, 1], src.view(torch.int32)[:, 1])             # one whole column
+    # and back: chunk -> a fresh Scalar4 array in one launch (whole rows)
+    back = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    from pgsd import _lib
+    jobs = (_lib.UnpackJob * 2)()
+    for i, (chunk, M, c0, bc) in enumerate(((out, 3, 0, 0), (w, 1, 3, 1))):
+        jobs[i].src = chunk.data_ptr()
+        jobs[i].src_type = 9 if i == 0 else 3
+        jobs[i].M = M
+        jobs[i].dst.dst = back.data_ptr()
+        jobs[i].dst.dst_type = 9
+        jobs[i].dst.dst_stride = 4
+        jobs[i].dst.dst_col0 = c0
+        jobs[i].dst.bitcast = bc
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_unpack_fields(2, jobs, N, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(back.view(torch.int32), src.view(torch.int32))
