@@ -1242,7 +1242,7 @@ extern "C" int pgsd_read_chunk(struct pgsd_handle* handle, void* data, const str
         return PGSD_ERROR_FILE_CORRUPT;
     if ((uint64_t)(c.location + size + stride) > (uint64_t)s->file_size)
         return PGSD_ERROR_FILE_CORRUPT;
-    pread_some(s->fd, data, size, c.location + (long long)stride);
+    pread_parallel(s->fd, data, size, c.location + (long long)stride);
     return PGSD_SUCCESS;
     }
 catch (...)

@@ -45,6 +45,7 @@ int pwrite_locked(int fd, const void* buf, size_t bytes, long long offset, bool 
 // plain full-length pwrite / pread loops (0 / -errno; pread leaves a short tail untouched)
 int pwrite_full(int fd, const void* buf, size_t bytes, long long offset);
 void pread_some(int fd, void* buf, size_t bytes, long long offset);
+void pread_parallel(int fd, void* buf, size_t bytes, long long offset); // >= 64 MiB: a few threads
 
 // ---- device pipeline (pgsd_device.cpp); created lazily by the first device call ----
 class DevicePipeline;

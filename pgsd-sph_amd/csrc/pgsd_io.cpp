@@ -85,6 +85,37 @@ void pread_some(int fd, void* buf, size_t bytes, long long offset)
         }
     }
 
+// Large host reads (restart files read on the CPU side) are split over a few short-lived
+// threads: page-cache reads take no exclusive lock and scale (profiles/r01_read_sweep.log).
+void pread_parallel(int fd, void* buf, size_t bytes, long long offset)
+    {
+    const size_t min_piece = (size_t)32 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t n = bytes / min_piece;
+    size_t cap = 8;
+    if (const char* e = getenv("PGSD_HOST_READ_THREADS"))
+        cap = (size_t)(atoi(e) > 0 ? atoi(e) : 1);
+    if (n > cap)
+        n = cap;
+    if (hw && n > hw)
+        n = hw;
+    if (n < 2)
+        {
+        pread_some(fd, buf, bytes, offset);
+        return;
+        }
+    const size_t piece = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (size_t off = piece; off < bytes; off += piece)
+        {
+        const size_t len = bytes - off < piece ? bytes - off : piece;
+        th.emplace_back([=] { pread_some(fd, (char*)buf + off, len, offset + (long long)off); });
+        }
+    pread_some(fd, buf, piece < bytes ? piece : bytes, offset);
+    for (auto& t : th)
+        t.join();
+    }
+
 class WriterPool
     {
     public:
