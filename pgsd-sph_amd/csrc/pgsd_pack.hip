@@ -1305,8 +1305,16 @@ static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, 
                 args.j[k].in_group = 1;
         args.g[args.n_groups++] = g;
         }
-    uint32_t tile = 16;
-    while (tile * 2 <= 1024 && (uint64_t)tile * 2 * sum_rowbytes <= UNPACK_LDS_BYTES)
+    // measured (profiles/r01_unpack_sweep.log): the unpack wants more resident workgroups than the
+    // pack -- 512-row tiles x 8 workgroups per CU beat 1024 x 4 by 8 % at 10 M rows; launches too small
+    // to fill the chip twice keep the larger tile
+    uint32_t tile = 16, tile_cap = N > (1ull << 21) ? 512 : 1024;
+    uint64_t per_cu = 8;
+    if (const char* e = getenv("PGSD_UNPACK_TILE")) // tuning sweeps (tools/unpack_bench.py)
+        tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
+    if (const char* e = getenv("PGSD_UNPACK_BLOCKS_PER_CU"))
+        per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
+    while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * sum_rowbytes <= UNPACK_LDS_BYTES)
         tile <<= 1;
     args.tile_rows = tile;
     args.n_tiles = (N + tile - 1) / tile;
@@ -1318,7 +1326,7 @@ static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, 
         }
     uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
     uint64_t blocks = args.n_tiles;
-    uint64_t cap = (uint64_t)num_cus() * std::max<uint64_t>(1, std::min<uint64_t>(4, resident));
+    uint64_t cap = (uint64_t)num_cus() * std::max<uint64_t>(1, std::min<uint64_t>(per_cu, resident));
     if (blocks > cap)
         blocks = cap;
     if (w32)
