@@ -371,7 +371,7 @@ torch.cuda.set_device(0)
 dist.init_process_group(backend=sys.argv[1], rank=0, world_size=1,
                         **({"device_id": torch.device("cuda", 0)} if sys.argv[1] == "nccl" else {}))
 import pgsd.dist as pdist
-name = pdist.init_from_torch(device=0, _single_rank_too=True)
+name = pdist.init_from_torch(device=0, _single_rank_too=True, prefer_rccl=sys.argv[2] == "1")
 counts, row0, n = pdist.partition_rows(12345)
 print(name, [int(c) for c in counts], row0, n)
 pdist.finalize()
@@ -380,16 +380,17 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("backend,expect", [("nccl", "rccl"), ("gloo", "torch-gloo")])
-def test_communicator_from_a_torch_process_group(backend, expect):
+@pytest.mark.parametrize("backend,prefer,expect", [("nccl", "1", "rccl"), ("nccl", "0", "torch-nccl"), ("gloo", "1", "torch-gloo")])
+def test_communicator_from_a_torch_process_group(backend, prefer, expect):
     """pgsd.dist.init_from_torch end to end in a one-rank group: the unique id travels through a
     torch broadcast, the library builds its own RCCL communicator next to PyTorch's, the self-check
     exchange and the cross-rank agreement run, and the row-count allgather works through it (the
-    multi-rank case needs more GPUs than the test box has)."""
+    multi-rank case needs more GPUs than the test box has). Second case: the fallback bench.py takes when
+    that communicator cannot be built -- host callbacks into torch.distributed on the same nccl group."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", RCCL_FROM_TORCH % os.path.join(root, "pgsd-sph_amd"), backend],
+    p = subprocess.run([sys.executable, "-c", RCCL_FROM_TORCH % os.path.join(root, "pgsd-sph_amd"), backend, prefer],
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert p.stdout.strip().splitlines()[-1] == "%s [12345] 0 12345" % expect, p.stdout
