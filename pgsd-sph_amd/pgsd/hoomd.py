@@ -386,6 +386,11 @@ class HOOMDTrajectory(object):
             self.file.write_chunk(chunk, data, None, rank, False)
         self._flush_device_fields(device_fields, part_dist, rank)
 
+        # state data: what the reference's writer sketches and leaves commented out
+        # (hoomd.py:634-636, upstream GSD's ``state/*`` chunks); replicated like the log
+        for state, data in frame.state.items():
+            self.file.write_chunk('state/' + state, numpy.ascontiguousarray(data), None, rank, False)
+
         # logged quantities are replicated
         for log, data in frame.log.items():
             self.file.write_chunk('log/' + log, data, None, rank, False)
@@ -537,6 +542,11 @@ class HOOMDTrajectory(object):
             elif self._initial_frame is not None and log[4:] in self._initial_frame.log:
                 snap.log[log[4:]] = self._initial_frame.log[log[4:]]
 
+        # state chunks belong to the frame they were written in (no fall-back, as upstream GSD reads them)
+        for state in self.file.find_matching_chunk_names('state/', False):
+            if self.file.chunk_exists(frame=idx, name=state, write_all=False):
+                snap.state[state[6:]] = self.file.read_chunk(frame=idx, name=state, offset=numpy.uint32(0), r_all=False)
+
         if self._initial_frame is None and idx == 0:
             self._initial_frame = snap
         return snap
@@ -629,6 +639,9 @@ class HOOMDTrajectory(object):
             fr = frame_of(log)
             if fr is not None:
                 snap.log[log[4:]] = f.read_chunk(fr, log)
+        for state in f.find_matching_chunk_names('state/', False):
+            if f.chunk_exists(idx, state):
+                snap.state[state[6:]] = f.read_chunk(idx, state)
         return snap
 
     def _read_scalar_any(self, idx, chunk, container, attr):

@@ -262,3 +262,21 @@ def test_random_trajectories_read_back_what_was_meant(seed, tmp_gsd):
                     assert 'e' not in s.log
                 else:
                     np.testing.assert_array_equal(s.log['e'], log)
+
+
+def test_state_chunks_round_trip(tmp_gsd):
+    """``Frame.state`` (hoomd.py:444,454; the writer half is commented out in the reference, :634-636)"""
+    with hoomd.open(tmp_gsd, 'w') as t:
+        for i in range(3):
+            f = make_frame(i)
+            if i != 1:
+                f.state['hpmc/sphere/radius'] = np.array([0.5, 0.25 + i], dtype=np.float32)
+                f.state['hpmc/integrate/d'] = np.array([0.1 * (i + 1)])
+            t.append(f)
+    for reader in (lambda: hoomd.open(tmp_gsd, 'r'),
+                   lambda: hoomd.HOOMDTrajectory(pypgsd.PGSDFile(open(tmp_gsd, 'rb')))):
+        with reader() as t:
+            np.testing.assert_array_equal(t[0].state['hpmc/sphere/radius'], np.array([0.5, 0.25], dtype=np.float32))
+            assert t[1].state == {}
+            np.testing.assert_array_equal(t[2].state['hpmc/sphere/radius'], np.array([0.5, 2.25], dtype=np.float32))
+            np.testing.assert_allclose(t[2].state['hpmc/integrate/d'], [0.3])
