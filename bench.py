@@ -115,6 +115,9 @@ def main():
                     help="pvi: position+velocity+typeid (headline); sph: the full PGSD-SPH particle schema, "
                          "112 B/particle in 15 chunks; union: plus the upstream HOOMD attributes, 164 B/particle "
                          "(BASELINE config 4 workloads)")
+    ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N>1: auto = the library's own RCCL communicator, torch.distributed callbacks if it cannot be "
+                         "built; rccl = no fallback; torch = callbacks only")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -144,13 +147,18 @@ def main():
     import pgsd.dist as pdist
     comm_backend = "self"
     if world > 1:
-        try:
-            # native RCCL communicator (ncclAllGather over xGMI issued from the C++ library)
-            comm_backend = pdist.init_from_torch(device=local_rank)
-        except RuntimeError as e:  # keep the run alive on a host-callback communicator
-            print("bench.py: RCCL communicator unavailable (%s); using torch.distributed callbacks" % e,
-                  file=sys.stderr)
+        if args.comm == "torch":
             comm_backend = pdist.init_from_torch(device=local_rank, prefer_rccl=False)
+        else:
+            try:
+                # native RCCL communicator (ncclAllGather over xGMI issued from the C++ library)
+                comm_backend = pdist.init_from_torch(device=local_rank)
+            except RuntimeError as e:  # keep the run alive on a host-callback communicator
+                if args.comm == "rccl":
+                    raise
+                print("bench.py: RCCL communicator unavailable (%s); using torch.distributed callbacks" % e,
+                      file=sys.stderr)
+                comm_backend = pdist.init_from_torch(device=local_rank, prefer_rccl=False)
 
     N = args.particles
     # HOOMD's own device layout (ParticleData: Scalar4 pos = x, y, z, __int_as_scalar(type);
