@@ -176,9 +176,11 @@ extern "C"
     /* reference pgsd.h:551-564.  `data` is HOST memory, borrowed for the call.
        N/M: this rank's rows/columns; N_global/M_global: what the index entry records;
        offset: element offset of this rank's first row inside the chunk;
-       global_size: elements in the whole chunk = sum over ranks of N*M (what both in-tree
-       callers pass: fl.pyx:649, benchmark-write.cc:99).  When all==true and global_size==0
-       the sum is obtained with one allgather instead. */
+       global_size: accepted and ignored, exactly as in the reference (pgsd.c:2147-2151 scales it
+       and never reads it again): the file advances by the SUM of the ranks' N*M*sizeof(type)
+       (MPI_Allreduce SUM, pgsd.c:2240-2246), here one 16-byte allgather per chunk that also
+       carries each rank's argument-check status, so a bad argument on one rank fails the call on
+       every rank instead of leaving the others inside a collective. */
     int pgsd_write_chunk(struct pgsd_handle* handle,
                          const char* name,
                          enum pgsd_type type,

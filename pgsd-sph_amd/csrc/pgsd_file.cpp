@@ -9,8 +9,9 @@
 //   ---------                                   ----
 //   names / index / buffer_index on rank 0      replicated on every rank (same calls in the
 //   only, scalars re-broadcast after each step    same order => same state), rank 0 writes them
-//   4 barriers + 3 allreduces + 2 bcasts per    per-particle chunk (all=true): none
-//   chunk (pgsd.c:2143-2257)                    replicated chunk (all=false): one 8-byte allgather
+//   4 barriers + 3 allreduces + 2 bcasts per    one 16-byte allgather per chunk: every rank's byte
+//   chunk (pgsd.c:2143-2257)                      count (-> max, sum, buffer sizes) + its local status;
+//                                                 pgsd_write_chunks_device: one for all its chunks
 //   ~15 collectives per pgsd_flush              one status allgather (+ one EOF exchange when
 //                                                 the on-disk index is relocated)
 //   MPI_File_write_at                           pwrite at the identical offset, split over a
@@ -745,9 +746,10 @@ struct Placement
     size_t size;           // bytes of this rank
     };
 
-static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uint32_t M,
-                       uint64_t N_global, uint32_t M_global, uint64_t offset, uint64_t global_size,
-                       bool all, uint8_t flags, bool have_data, Placement* pl)
+// Local argument checks of pgsd_write_chunk, pgsd.c:2090-2105.  The reference returns from them
+// before its first collective, which leaves the other ranks waiting; here the verdict travels
+// with the size exchange below, so every rank returns the same error.
+static int check_chunk_args(const Impl* s, const char* name, uint64_t N, uint32_t M, uint8_t flags, bool have_data)
     {
     if (N > 0 && !have_data)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -759,7 +761,50 @@ static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uin
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (!name)
         return PGSD_ERROR_INVALID_ARGUMENT;
+    return PGSD_SUCCESS;
+    }
 
+// The one exchange of a chunk write: every rank's byte count (or row count) and the status of its
+// local preparation.  The reference obtains max and sum of `size` with MPI_Allreduce MAX
+// (pgsd.c:2157) and SUM (pgsd.c:2242) and never looks at the caller's global_size
+// (pgsd.c:2147-2151 only scales it), so neither does this library: the file advances by what the
+// ranks actually contribute.  Returns the first non-zero status in rank order.
+static int exchange_counts(Impl* s, uint64_t mine, int local_rc, std::vector<uint64_t>& all)
+    {
+    all.assign((size_t)s->P, 0);
+    if (s->P == 1)
+        {
+        all[0] = mine;
+        return local_rc;
+        }
+    uint64_t send[2] = {mine, (uint64_t)(uint32_t)local_rc | ((uint64_t)(uint32_t)(local_rc ? errno : 0) << 32)};
+    std::vector<uint64_t> recv((size_t)s->P * 2);
+    if (s->comm.allgather(s->comm.ctx, send, recv.data(), sizeof(send)) != 0)
+        {
+        set_last_error("communicator allgather failed");
+        return PGSD_ERROR_COMM;
+        }
+    int rc = PGSD_SUCCESS;
+    for (int r = 0; r < s->P; r++)
+        {
+        all[(size_t)r] = recv[(size_t)r * 2];
+        const int rrc = (int)(int32_t)(uint32_t)recv[(size_t)r * 2 + 1];
+        if (rrc != 0 && rc == PGSD_SUCCESS)
+            {
+            rc = rrc;
+            if (local_rc == 0)
+                errno = (int)(uint32_t)(recv[(size_t)r * 2 + 1] >> 32);
+            }
+        }
+    return rc;
+    }
+
+// Decide where a chunk's bytes go exactly as pgsd_write_chunk decides (pgsd.c:2143-2256) and record
+// its index entry.  `sizes` holds every rank's byte count of the chunk (exchange_counts).
+static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uint32_t M, uint64_t N_global,
+                       uint32_t M_global, uint64_t offset, bool all, const std::vector<uint64_t>& sizes,
+                       Placement* pl)
+    {
     uint16_t id;
     int rc = name_to_id(s, name, &id);
     if (rc != PGSD_SUCCESS)
@@ -774,38 +819,15 @@ static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uin
     entry.M = M_global;
 
     const size_t sz = sizeof_type(type);
-    const size_t size = (size_t)(N * M * sz);
-    pl->size = size;
+    pl->size = (size_t)(N * M * sz);
 
-    // max and sum of `size` over the ranks (MPI_Allreduce MAX pgsd.c:2157, SUM pgsd.c:2242)
-    uint64_t maxsize = size, sumsize = size;
-    std::vector<uint64_t> sizes;
-    if (s->P > 1)
+    uint64_t maxsize = 0, sumsize = 0;
+    for (uint64_t v : sizes)
         {
-        if (all && global_size != 0)
-            {
-            // per-particle chunk: the caller already knows the global element count
-            // (fl.pyx:649, benchmark-write.cc:99), no exchange needed
-            sumsize = global_size * sz;
-            maxsize = sumsize; // only compared when !all
-            }
-        else
-            {
-            rc = s->allgather_u64(size, sizes);
-            if (rc != PGSD_SUCCESS)
-                return rc;
-            maxsize = 0;
-            sumsize = 0;
-            for (uint64_t v : sizes)
-                {
-                if (v > maxsize)
-                    maxsize = v;
-                sumsize += v;
-                }
-            }
+        if (v > maxsize)
+            maxsize = v;
+        sumsize += v;
         }
-    else
-        sizes.assign(1, size);
 
     if (maxsize < s->maxbuf && !all)
         {
@@ -832,13 +854,26 @@ static int place_chunk(Impl* s, const char* name, uint32_t type, uint64_t N, uin
         pl->buffered = false;
         pl->write = all || s->rank == 0;
         pl->file_offset = s->file_size + (long long)(offset * sz);
-        // file_size advances by the sum over all ranks even when only rank 0 wrote
-        // (all == false): the hole is part of the reference's layout (pgsd.c:2240-2249)
+        // file_size advances by the sum of the ranks' sizes (MPI_Allreduce SUM, pgsd.c:2240-2249):
+        // also when only rank 0 wrote (all == false: the hole is part of the reference's layout)
+        // and whatever the caller passed as global_size (replicated data written with all == true
+        // and offset 0, fl.pyx's default arguments, advances the file by P copies)
         s->file_size += (long long)sumsize;
         s->dirty_data = true;
         }
     s->pending++;
     return PGSD_SUCCESS;
+    }
+
+// a chunk this rank could not deliver after its placement was committed: the index entry exists on
+// every rank, so the failure is reported by all of them at the next flush (agree_status)
+static void remember_failure(Impl* s, int rc, int err)
+    {
+    if (s->sticky_rc == PGSD_SUCCESS)
+        {
+        s->sticky_rc = rc;
+        s->sticky_errno = err;
+        }
     }
 
 static int ensure_device(Impl* s)
@@ -1084,9 +1119,13 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
     Impl* s = impl_of(handle);
     if (!s)
         return PGSD_ERROR_INVALID_ARGUMENT;
+    (void)global_size; // dead in the reference as well (pgsd.c:2147-2151)
+    const int local = check_chunk_args(s, name, N, M, flags, data != NULL);
+    std::vector<uint64_t> sizes;
+    int rc = exchange_counts(s, local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0, local, sizes);
     Placement pl;
-    int rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, global_size, all,
-                         flags, data != NULL, &pl);
+    if (rc == PGSD_SUCCESS)
+        rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, all, sizes, &pl);
     if (rc == PGSD_SUCCESS)
         {
         if (pl.buffered)
@@ -1103,11 +1142,7 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
                 {
                 errno = -e;
                 rc = PGSD_ERROR_IO;
-                if (s->sticky_rc == PGSD_SUCCESS)
-                    {
-                    s->sticky_rc = rc;
-                    s->sticky_errno = -e;
-                    }
+                remember_failure(s, rc, -e);
                 }
             }
         }
@@ -1417,18 +1452,19 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
     Impl* s = impl_of(handle);
     if (!s)
         return PGSD_ERROR_INVALID_ARGUMENT;
-    if (N > 0)
-        {
-        int rc = check_field(src, (uint32_t)type, M);
-        if (rc != PGSD_SUCCESS)
-            return rc;
-        }
-    int rc = ensure_device(s);
-    if (rc != PGSD_SUCCESS)
-        return rc;
+    (void)global_size;
+    // everything that can fail on this rank alone comes first and travels with the exchange:
+    // a rank without a usable device or with a bad field makes the call fail on every rank
+    int local = check_chunk_args(s, name, N, M, flags, N == 0 || (src && src->src));
+    if (local == PGSD_SUCCESS && N > 0)
+        local = check_field(src, (uint32_t)type, M);
+    if (local == PGSD_SUCCESS)
+        local = ensure_device(s);
+    std::vector<uint64_t> sizes;
+    int rc = exchange_counts(s, local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0, local, sizes);
     Placement pl;
-    rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, global_size, all, flags,
-                     N == 0 || (src && src->src), &pl);
+    if (rc == PGSD_SUCCESS)
+        rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, all, sizes, &pl);
     if (rc == PGSD_SUCCESS && pl.size > 0 && (pl.buffered || pl.write))
         {
         std::vector<DeviceChunk> chunks(1);
@@ -1450,7 +1486,12 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
         std::string err;
         rc = device_pipeline_submit(s->dev, chunks, N, &err);
         if (rc != PGSD_SUCCESS)
+            {
             set_last_error(err);
+            remember_failure(s, rc, 0);
+            if (pl.buffered) // the buffer must keep the length every rank has accounted for
+                s->write_buffer.insert(s->write_buffer.end(), pl.size, 0);
+            }
         else if (pl.buffered)
             s->write_buffer.insert(s->write_buffer.end(), tmp.begin(), tmp.end());
         }
@@ -1470,27 +1511,28 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
     Impl* s = impl_of(handle);
     if (!s || !reqs || n_chunks == 0)
         return PGSD_ERROR_INVALID_ARGUMENT;
-    for (uint32_t i = 0; i < n_chunks; i++)
+    int local = PGSD_SUCCESS;
+    for (uint32_t i = 0; i < n_chunks && local == PGSD_SUCCESS; i++)
         {
-        if (!reqs[i].name)
-            return PGSD_ERROR_INVALID_ARGUMENT;
-        if (N > 0)
-            {
-            int rc = check_field(&reqs[i].src, reqs[i].type, reqs[i].M);
-            if (rc != PGSD_SUCCESS)
-                return rc;
-            }
+        local = check_chunk_args(s, reqs[i].name, N, reqs[i].M, 0, N == 0 || reqs[i].src.src);
+        if (local == PGSD_SUCCESS && N > 0)
+            local = check_field(&reqs[i].src, reqs[i].type, reqs[i].M);
         }
-    int rc = ensure_device(s);
-    if (rc != PGSD_SUCCESS)
-        return rc;
+    if (local == PGSD_SUCCESS)
+        local = ensure_device(s);
+    // ONE exchange for all chunks of the call: they share the row count, so every rank's byte
+    // count of chunk i is rows[r] * M_i * sizeof(type_i)
+    std::vector<uint64_t> rows;
+    int rc = exchange_counts(s, N, local, rows);
     std::vector<DeviceChunk> chunks;
+    std::vector<uint64_t> sizes((size_t)s->P);
     for (uint32_t i = 0; i < n_chunks && rc == PGSD_SUCCESS; i++)
         {
         const pgsd_chunk_req& q = reqs[i];
+        for (int r = 0; r < s->P; r++)
+            sizes[(size_t)r] = rows[(size_t)r] * q.M * sizeof_type(q.type);
         Placement pl;
-        rc = place_chunk(s, q.name, q.type, N, q.M, N_global, q.M, offset_rows * q.M,
-                         N_global * (uint64_t)q.M, true, 0, true, &pl);
+        rc = place_chunk(s, q.name, q.type, N, q.M, N_global, q.M, offset_rows * q.M, true, sizes, &pl);
         if (rc == PGSD_SUCCESS && pl.size > 0)
             {
             DeviceChunk c;
@@ -1508,7 +1550,10 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
         std::string err;
         rc = device_pipeline_submit(s->dev, chunks, N, &err);
         if (rc != PGSD_SUCCESS)
+            {
             set_last_error(err);
+            remember_failure(s, rc, 0);
+            }
         }
     publish(handle, s);
     return rc;

@@ -31,6 +31,14 @@
  *   chunk <name> <u8|u16|u32|u64|i8|i16|i32|i64|f32|f64> <M> <all 0|1> <dist>
  *         dist = even:<Nglobal> | same:<N> | list:<n0>,<n1>,...   (list is cycled over ranks)
  *   rawchunk <name> <type> <N> <M> <N_global> <M_global> <offset> <global_size> <all>
+ *         (every rank passes these very arguments; the data differs per rank)
+ *   samechunk <name> <type> <N> <M> <N_global> <M_global> <offset> <global_size> <all>
+ *         (as rawchunk with the SAME data on every rank: with all=1 and offset=0 this is what
+ *          fl.pyx's write_chunk(name, data) passes by default, fl.pyx:526, 592-598, 640-652 --
+ *          the ranks' writes overlap, identical bytes keep the file deterministic)
+ *   chunkgs <name> <type> <M> <all> <dist> <global_size>
+ *         (as chunk, but the caller's global_size argument is the given value, right or wrong:
+ *          the reference ignores it, pgsd.c:2147-2151, 2240-2246)
  *   end_frame | flush | close | dump
  *   maxbuf <bytes> | idxbuf <entries>
  *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
@@ -271,7 +279,28 @@ int main(int argc, char** argv)
                 }
             free(data);
             }
-        else if (strcmp(cmd, "rawchunk") == 0 && nt == 10)
+        else if (strcmp(cmd, "chunkgs") == 0 && nt == 7)
+            {
+            size_t sz;
+            int type = parse_type(tok[2], &sz);
+            uint32_t M = (uint32_t)strtoul(tok[3], NULL, 10);
+            int all = atoi(tok[4]);
+            uint64_t gs = strtoull(tok[6], NULL, 10);
+            uint64_t counts[1024] = {0};
+            dist_counts(tok[5], counts);
+            uint64_t N = counts[g_rank], Ng = 0, row0 = 0;
+            for (int r = 0; r < g_size; r++)
+                {
+                Ng += counts[r];
+                if (r < g_rank)
+                    row0 += counts[r];
+                }
+            void* data = gen_data(type, seed, row0, N, M, sz);
+            rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M, gs, all != 0, 0,
+                                  data);
+            free(data);
+            }
+        else if ((strcmp(cmd, "rawchunk") == 0 || strcmp(cmd, "samechunk") == 0) && nt == 10)
             {
             size_t sz;
             int type = parse_type(tok[2], &sz);
@@ -282,7 +311,7 @@ int main(int argc, char** argv)
             uint64_t off = strtoull(tok[7], NULL, 10);
             uint64_t gs = strtoull(tok[8], NULL, 10);
             int all = atoi(tok[9]);
-            void* data = gen_data(type, seed + (uint64_t)g_rank, 0, N, M, sz);
+            void* data = gen_data(type, cmd[0] == 's' ? seed : seed + (uint64_t)g_rank, 0, N, M, sz);
             rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, Mg, off, gs,
                                   all != 0, 0, data);
             free(data);

@@ -216,10 +216,18 @@ def run_oracle(script, out_path, P):
                 # each rank passes N_global = its own N (fl.pyx:594); entry uses root's
                 rc = oracle_write_chunk(lib, h, name, t, arrays, M, counts[0], M, [0] * P,
                                         [counts[r] * M for r in range(P)], False)
-        elif cmd == "rawchunk":
+        elif cmd == "chunkgs":
+            name, t, M, all_, dist, gs = tok[1], TYPE_IDS[tok[2]], int(tok[3]), int(tok[4]), tok[5], int(tok[6])
+            counts = dist_counts(dist, P)
+            Ng = sum(counts)
+            row0 = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(int)
+            arrays = [gen_data(t, seed, int(row0[r]), counts[r], M) for r in range(P)]
+            rc = oracle_write_chunk(lib, h, name, t, arrays, M, Ng, M, [int(row0[r]) * M for r in range(P)],
+                                    [gs] * P, all_)
+        elif cmd in ("rawchunk", "samechunk"):
             name, t = tok[1], TYPE_IDS[tok[2]]
             N, M, Ng, Mg, off, gs, all_ = (int(x) for x in tok[3:10])
-            arrays = [gen_data(t, seed + r, 0, N, M) for r in range(P)]
+            arrays = [gen_data(t, seed if cmd == "samechunk" else seed + r, 0, N, M) for r in range(P)]
             rc = oracle_write_chunk(lib, h, name, t, arrays, M, Ng, Mg, [off] * P, [gs] * P, all_)
         elif cmd == "end_frame":
             rc = lib.oracle_end_frame(h)

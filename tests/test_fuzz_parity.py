@@ -36,6 +36,7 @@ def make_script(seed, P):
     for frame in range(n_frames):
         lines.append("seed %d" % rng.randint(0, 10 ** 6))
         used = set()
+        hole = False
         for _ in range(rng.randint(0, 9)):
             name = rng.choice(names)
             if name in used and rng.random() < 0.9:
@@ -43,7 +44,23 @@ def make_script(seed, P):
             used.add(name)
             t = rng.choice(TYPES)
             M = rng.randint(1, 4)
-            if rng.random() < 0.55:
+            shape = rng.random()
+            if shape < 0.12:
+                # fl.pyx's default arguments (write_chunk(name, data): all=1, offset=0, N_global=N,
+                # global_size=N*M on every rank, fl.pyx:526, 592-598, 640-652): replicated rows on the
+                # direct path, the file advances by the SUM of the ranks' sizes (pgsd.c:2240-2246)
+                n = rng.randint(1, 30)
+                gs = rng.choice([n * M, n * M, 0, 1, 10 ** 9])
+                lines.append("samechunk %s %s %d %d %d %d 0 %d 1" % (name, t, n, M, n, M, gs))
+                hole = True
+            elif shape < 0.22:
+                # a proper partition with a global_size that is not the sum (dead argument, pgsd.c:2147-2151)
+                if rng.random() < 0.4:
+                    dist = "list:" + ",".join(str(rng.choice([0, 0, 1, 3, 17, 40])) for _ in range(P))
+                else:
+                    dist = "even:%d" % rng.randint(0, 120)
+                lines.append("chunkgs %s %s %d 1 %s %d" % (name, t, M, dist, rng.choice([0, 1, 7, 10 ** 12])))
+            elif shape < 0.60:
                 if rng.random() < 0.3:
                     dist = "list:" + ",".join(str(rng.choice([0, 0, 1, 3, 17, 40])) for _ in range(P))
                 else:
@@ -63,6 +80,11 @@ def make_script(seed, P):
                 lines.append("chunk %s %s %d 0 same:%d" % (name, t, M, n))
             if rng.random() < 0.05:
                 lines.append("flush")
+        if hole and P > 1:
+            # replicated rows written with all=1 leave the file shorter than file_size (P-1 copies'
+            # worth of hole); data behind the hole keeps the file as long as its index says, which
+            # the reference needs on re-open (see the seed-114 note above)
+            lines.append("chunk fuzz/tail u32 1 1 even:%d" % (P + rng.randint(0, 5)))
         lines.append("end_frame")
         r = rng.random()
         if r < 0.25:

@@ -50,6 +50,16 @@ def _worker(rank, world, port, path, counts, mode):
             assert f.chunk_exists(frame, 'particles/position')
             assert f.read_chunk(frame, 'particles/N')[0] == n_global
         f.close()
+    elif mode == "fl_defaults":
+        # write_chunk(name, data) exactly as the reference's binding is called by default
+        # (fl.pyx:526 write_all=True, offset=None, rank=0): replicated rows on the direct path
+        f = fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+        for frame in range(2):
+            f.write_chunk('log/energy', S.gen_data(9, 70 + frame, 0, 10, 3))
+            f.write_chunk('log/count', S.gen_data(3, 80 + frame, 0, 7, 1)[:, 0])
+            f.write_chunk('particles/position', S.gen_data(9, 90 + frame, row0, n, 3), offset=got_counts, rank=rank)
+            f.end_frame()
+        f.close()
     else:
         t = hoomd.open(path, 'w')
         for frame in range(2):
@@ -109,6 +119,41 @@ def test_fl_two_and_three_ranks_match_oracle(counts, tmp_path):
             ('particles/typeid', 3, 1, True, [S.gen_data(3, seed, int(row0[r]), counts[r], 1) for r in range(P)]),
         ])
     _oracle_file(ref, P, frames)
+    with open(mine, 'rb') as a, open(ref, 'rb') as b:
+        assert a.read() == b.read()
+
+
+@pytest.mark.parametrize("counts", [[5, 9], [4, 0, 7]])
+def test_fl_write_chunk_default_arguments_match_oracle(counts, tmp_path):
+    """`write_chunk(name, data)` with the binding's default arguments on every rank: all=1, offset 0,
+    N_global = N, global_size = N*M (fl.pyx:592-598, 640-652).  The reference advances the file by the
+    SUM of the ranks' sizes (pgsd.c:2240-2246), P copies' worth for replicated data; round 1's
+    product trusted global_size and diverged at P > 1.  The oracle's handling
+    of this call shape is pinned to reference-written files by tests/golden/scenarios/defaultargs.scn."""
+    P = len(counts)
+    mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
+    tmp_mp.spawn(_worker, args=(P, free_port(), mine, counts, "fl_defaults"), nprocs=P, join=True)
+    row0 = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(int)
+    lib = S.oracle_lib()
+    rc = ctypes.c_int(0)
+    h = lib.oracle_create_and_open(ref.encode(), P, b'app', b'hoomd', lib.oracle_make_version(1, 4), 1, 0,
+                                   ctypes.byref(rc))
+    assert rc.value == 0
+    sizes = []
+    for frame in range(2):
+        e = S.gen_data(9, 70 + frame, 0, 10, 3)
+        c = S.gen_data(3, 80 + frame, 0, 7, 1)
+        assert S.oracle_write_chunk(lib, h, 'log/energy', 9, [e] * P, 3, 10, 3, [0] * P, [30] * P, True) == 0
+        assert S.oracle_write_chunk(lib, h, 'log/count', 3, [c] * P, 1, 7, 1, [0] * P, [7] * P, True) == 0
+        pos = [S.gen_data(9, 90 + frame, int(row0[r]), counts[r], 3) for r in range(P)]
+        Ng = sum(counts)
+        assert S.oracle_write_chunk(lib, h, 'particles/position', 9, pos, 3, Ng, 3, [int(x) * 3 for x in row0],
+                                    [Ng * 3] * P, True) == 0
+        assert lib.oracle_end_frame(h) == 0
+        sizes.append(lib.oracle_get_file_size(h))
+    assert lib.oracle_close(h) == 0
+    # P copies' worth of the replicated chunks per frame: (120 + 28) * P + 12 * Ng
+    assert sizes[0] == 5376 + (120 + 28) * P + 12 * sum(counts)
     with open(mine, 'rb') as a, open(ref, 'rb') as b:
         assert a.read() == b.read()
 
