@@ -35,7 +35,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 namespace pgsd_amd
@@ -538,6 +540,228 @@ template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack
         }
     }
 
+// ------------------------------------------------------------------ row-per-lane pack (the default)
+// One particle row per lane, no LDS, no barrier: lane i loads row i of a source array with one
+// (or two) vector loads and stores the M elements of every chunk fed by that array as ONE
+// contiguous piece of M * sizeof(element) bytes at row i of the chunk.  Consecutive lanes hold
+// consecutive rows, so every wave instruction still covers one contiguous span of memory --
+// 1 KiB per float4 load, 768 B per N x 3 float store, 256 B per scalar store, all of them whole
+// 128-byte lines -- which is what the memory system needs; the 16-byte-per-lane rule is not.
+// Measured on MI355X (tools/pack_lab.hip, profiles/r02_pack_lab*.jsonl): this shape runs the
+// headline workload at the rate of a bare register float4 copy of the same bytes (93-95 us for
+// 600 MB at 10 M particles), where the LDS-staged tile kernel below needs 104-107 us: the
+// stage -> barrier -> emit phases cost more than the odd store widths.
+// Workgroups are dealt to source arrays group-major (all workgroups of array 0, then array 1 ...):
+// a wave keeps one input and at most a few output streams open.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+// rows of 12 or 24 bytes are only dword / 8-byte aligned
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+// a source row in registers: two SSA vectors (a C array indexed by a run-time column would be
+// demoted to scratch memory by the compiler)
+struct RowRegs
+    {
+    u32x4 lo, hi;
+    };
+
+template<int RW> __device__ __forceinline__ void row_load(const uint32_t* p, RowRegs& r)
+    {
+    if constexpr (RW == 1)
+        r.lo.x = __builtin_nontemporal_load(p);
+    else if constexpr (RW == 2)
+        {
+        u32x2 v = __builtin_nontemporal_load((const u32x2_a4*)p);
+        r.lo.x = v.x, r.lo.y = v.y;
+        }
+    else if constexpr (RW == 3)
+        {
+        u32x3 v = __builtin_nontemporal_load((const u32x3_a4*)p);
+        r.lo.x = v.x, r.lo.y = v.y, r.lo.z = v.z;
+        }
+    else
+        {
+        r.lo = __builtin_nontemporal_load((const u32x4_a4*)p);
+        if constexpr (RW == 6)
+            {
+            u32x2 w = __builtin_nontemporal_load((const u32x2_a4*)(p + 4));
+            r.hi.x = w.x, r.hi.y = w.y;
+            }
+        else if constexpr (RW == 8)
+            r.hi = __builtin_nontemporal_load((const u32x4_a4*)(p + 4));
+        }
+    }
+
+// dword `i` (wave-uniform) of a row held in registers
+template<int RW> __device__ __forceinline__ uint32_t row_pick(const RowRegs& r, uint32_t i)
+    {
+    if constexpr (RW == 1)
+        return r.lo.x;
+    else if constexpr (RW == 2)
+        return (i & 1u) ? r.lo.y : r.lo.x;
+    else if constexpr (RW <= 4)
+        {
+        const uint32_t a = (i & 1u) ? r.lo.y : r.lo.x, b = (i & 1u) ? r.lo.w : r.lo.z;
+        return (i & 2u) ? b : a;
+        }
+    else
+        {
+        const uint32_t a = (i & 1u) ? r.lo.y : r.lo.x, b = (i & 1u) ? r.lo.w : r.lo.z;
+        const uint32_t c = (i & 1u) ? r.hi.y : r.hi.x, d = (i & 1u) ? r.hi.w : r.hi.z;
+        const uint32_t ab = (i & 2u) ? b : a, cd = (i & 2u) ? d : c;
+        return (i & 4u) ? cd : ab;
+        }
+    }
+
+// nw (1..8, wave-uniform) dwords to row `i` of a chunk whose rows are nw dwords long
+template<uint32_t NWMAX>
+__device__ __forceinline__ void row_store(uint32_t* p, const uint32_t (&w)[ROWS_MAX_WORDS], uint32_t nw)
+    {
+    if (NWMAX >= 4 && nw >= 4)
+        {
+        u32x4 v = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(v, (u32x4_a4*)p);
+        if (NWMAX == 4)
+            return;
+        if (nw == 8)
+            {
+            u32x4 q = {w[4], w[5], w[6], w[7]};
+            __builtin_nontemporal_store(q, (u32x4_a4*)(p + 4));
+            }
+        else if (nw == 6)
+            {
+            u32x2 q = {w[4], w[5]};
+            __builtin_nontemporal_store(q, (u32x2_a4*)(p + 4));
+            }
+        else if (nw == 5)
+            __builtin_nontemporal_store(w[4], p + 4);
+        else if (nw == 7)
+            {
+            u32x3 q = {w[4], w[5], w[6]};
+            __builtin_nontemporal_store(q, (u32x3_a4*)(p + 4));
+            }
+        }
+    else if (nw == 3)
+        {
+        u32x3 v = {w[0], w[1], w[2]};
+        __builtin_nontemporal_store(v, (u32x3_a4*)p);
+        }
+    else if (nw == 2)
+        {
+        u32x2 v = {w[0], w[1]};
+        __builtin_nontemporal_store(v, (u32x2_a4*)p);
+        }
+    else
+        __builtin_nontemporal_store(w[0], p);
+    }
+
+// BITS_ONLY: every chunk of the launch moves dwords unchanged (the common case: float4 -> N x 3
+// floats, the type id in position.w, int3 images); no conversion code is generated
+template<int RW, bool BITS_ONLY>
+__device__ __forceinline__ void row_emit(const RowsOut& o, const RowRegs& r, uint64_t i)
+    {
+    uint32_t w[ROWS_MAX_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t nw = o.nw_out, c0 = o.col0; // c0: first source dword
+    constexpr uint32_t NWMAX = BITS_ONLY ? (RW < ROWS_MAX_WORDS ? RW : ROWS_MAX_WORDS) : ROWS_MAX_WORDS;
+    if (BITS_ONLY || o.kind == ROWS_BITS)
+        {
+        // picks past the chunk's width are computed and dropped: cheaper than guarding them
+#pragma unroll
+        for (uint32_t k = 0; k < NWMAX; k++)
+            w[k] = row_pick<RW>(r, c0 + k);
+        }
+    else if (o.kind == ROWS_F64_F32)
+        {
+        if constexpr (RW >= 2)
+            {
+#pragma unroll
+            for (uint32_t k = 0; k < RW / 2; k++)
+                {
+                const uint64_t bits = (uint64_t)row_pick<RW>(r, c0 + 2 * k) | ((uint64_t)row_pick<RW>(r, c0 + 2 * k + 1) << 32);
+                w[k] = __float_as_uint((float)__longlong_as_double((long long)bits)); // v_cvt_f32_f64, RNE
+                }
+            }
+        }
+    else // ROWS_F32_F64
+        {
+#pragma unroll
+        for (uint32_t k = 0; k < (RW < 4 ? RW : 4); k++)
+            {
+            const uint64_t bits = (uint64_t)__double_as_longlong((double)__uint_as_float(row_pick<RW>(r, c0 + k)));
+            w[2 * k] = (uint32_t)bits;
+            w[2 * k + 1] = (uint32_t)(bits >> 32);
+            }
+        }
+    row_store<NWMAX>((uint32_t*)o.dst + i * nw, w, nw);
+    }
+
+// Row mode: blockIdx.y = source array (group), blockIdx.x = block of T*U consecutive rows.  The
+// dispatcher walks x fastest, so the launch streams array after array (group-major).
+template<int T, int U, int RW, bool BITS_ONLY>
+__global__ __launch_bounds__(T) void pack_rows_kernel(const RowsArgs args)
+    {
+    const RowsGroup& g = args.g[blockIdx.y];
+    RowRegs r[U];
+    const uint64_t N = args.N;
+    const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
+    const uint32_t* order = g.order;
+    const uint32_t* src = (const uint32_t*)g.src;
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        r[k].lo = u32x4 {0, 0, 0, 0};
+        r[k].hi = u32x4 {0, 0, 0, 0};
+        const uint64_t i = base + (uint64_t)k * T;
+        if (i < N)
+            {
+            const uint64_t srow = order ? (uint64_t)__builtin_nontemporal_load(order + i) : i;
+            row_load<RW>(src + srow * RW, r[k]);
+            }
+        }
+    const uint32_t n_out = g.n_out;
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t i = base + (uint64_t)k * T;
+        if (i < N)
+            for (uint32_t oi = 0; oi < n_out; oi++)
+                row_emit<RW, BITS_ONLY>(g.out[oi], r[k], i);
+        }
+    }
+
+// Copy mode: dense chunks of the source's own type (the chunk IS the array: scalar arrays,
+// orientation, ...), 16 bytes per lane.  blockIdx.y = array, arrays shorter than the longest one of
+// the launch leave their surplus workgroups at once.
+template<int T, int U> __global__ __launch_bounds__(T) void pack_copy_kernel(const RowsArgs args)
+    {
+    const RowsGroup& g = args.g[blockIdx.y];
+    const u32x4* src = (const u32x4*)g.src;
+    u32x4* dst = (u32x4*)g.out[0].dst;
+    const uint64_t nvec = g.copy_vecs;
+    const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
+    if (base - threadIdx.x >= nvec && !(blockIdx.x == 0 && g.copy_tail))
+        return;
+    u32x4 r[U];
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t v = base + (uint64_t)k * T;
+        if (v < nvec)
+            r[k] = __builtin_nontemporal_load(src + v);
+        }
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t v = base + (uint64_t)k * T;
+        if (v < nvec)
+            __builtin_nontemporal_store(r[k], dst + v);
+        }
+    if (blockIdx.x == 0 && threadIdx.x < g.copy_tail)
+        ((char*)dst)[nvec * 16 + threadIdx.x] = ((const char*)src)[nvec * 16 + threadIdx.x];
+    }
+
 // Fallback for operands the tiled kernel cannot take (unaligned pointers, very wide
 // rows): one output element per lane, grid-stride.  Correct for everything, not tuned.
 __global__ __launch_bounds__(PACK_THREADS) void pack_generic_kernel(const PackGenericArgs a)
@@ -1008,21 +1232,109 @@ static void launch_variant(bool waves, bool prefetch, int mode, int var, unsigne
         launch_mode<PACK_MODE_GENERIC>(waves, (var & VAR_GLDS), blocks, lds_bytes, stream, args, ev_start, ev_stop);
     }
 
-struct PendingLaunch
+// ---- row-per-lane launches
+struct RowsCfg
     {
-    bool waves;
-    bool prefetch;
-    int mode, var;
-    unsigned blocks;
-    size_t lds_bytes;
-    PackArgs args;
+    int T, U;
     };
+
+static RowsCfg rows_config(uint64_t N, uint32_t n_groups)
+    {
+    // measured, interleaved launch by launch in one process (profiles/r02_pack_ab.jsonl): 256 threads x 2
+    // rows per lane is the best or within 1-2 % of the best for every workload from 1 M rows up
+    // (10 M particles, HOOMD layout: 94.8 us against 106.5 us for the LDS-tiled kernel); a launch of one
+    // or two arrays below 2 M rows does better with half as many, fatter workgroups
+    RowsCfg c = (N < (2u << 20) && n_groups <= 2) ? RowsCfg {256, 4} : RowsCfg {256, 2};
+    if (const char* e = getenv("PGSD_PACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
+        {
+        int t = 0, u = 0;
+        if (sscanf(e, "%dx%d", &t, &u) == 2)
+            c = RowsCfg {t, u};
+        }
+    return c;
+    }
+
+template<int T, int U>
+static void launch_rows_tu(const RowsArgs& a, bool copy, uint32_t rw, bool bits_only, hipStream_t stream, hipEvent_t e0,
+                           hipEvent_t e1)
+    {
+    const dim3 grid((unsigned)a.n_blocks, a.n_groups);
+    if (copy)
+        {
+        hipExtLaunchKernelGGL((pack_copy_kernel<T, U>), grid, dim3(T), 0, stream, e0, e1, 0, a);
+        return;
+        }
+#define ROWS_LAUNCH(RW)                                                                                       \
+    if (bits_only)                                                                                            \
+        hipExtLaunchKernelGGL((pack_rows_kernel<T, U, RW, true>), grid, dim3(T), 0, stream, e0, e1, 0, a);    \
+    else                                                                                                      \
+        hipExtLaunchKernelGGL((pack_rows_kernel<T, U, RW, false>), grid, dim3(T), 0, stream, e0, e1, 0, a)
+    switch (rw)
+        {
+        case 1: ROWS_LAUNCH(1); break;
+        case 2: ROWS_LAUNCH(2); break;
+        case 3: ROWS_LAUNCH(3); break;
+        case 4: ROWS_LAUNCH(4); break;
+        case 6: ROWS_LAUNCH(6); break;
+        default: ROWS_LAUNCH(8); break;
+        }
+#undef ROWS_LAUNCH
+    }
+
+static void launch_rows(const RowsCfg& c, const RowsArgs& a, bool copy, uint32_t rw, bool bits_only, hipStream_t stream,
+                        hipEvent_t e0, hipEvent_t e1)
+    {
+    if (c.T == 256 && c.U == 4)
+        launch_rows_tu<256, 4>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 256 && c.U == 2)
+        launch_rows_tu<256, 2>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 256 && c.U == 1)
+        launch_rows_tu<256, 1>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 128 && c.U == 2)
+        launch_rows_tu<128, 2>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 64 && c.U == 2)
+        launch_rows_tu<64, 2>(a, copy, rw, bits_only, stream, e0, e1);
+    else
+        launch_rows_tu<128, 1>(a, copy, rw, bits_only, stream, e0, e1);
+    }
+
+// Can the row-per-lane kernel take this job?  4- and 8-byte elements moved unchanged or converted
+// between f32 and f64, source rows and chunk rows of at most 8 dwords, 16-byte aligned arrays.
+static bool rows_eligible(const pgsd_pack_job& j, uint64_t N, uint32_t* kind_out)
+    {
+    const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type), dsz = (uint32_t)sizeof_type(j.dst_type);
+    if ((ssz != 4 && ssz != 8) || (dsz != 4 && dsz != 8))
+        return false;
+    const uint32_t kind = conv_kind(j.src.src_type, j.dst_type, j.src.bitcast);
+    uint32_t rk;
+    if (kind == PACK_BITS && ssz == dsz)
+        rk = ROWS_BITS;
+    else if (kind == PACK_F2F && ssz == 8 && dsz == 4)
+        rk = ROWS_F64_F32;
+    else if (kind == PACK_F2F && ssz == 4 && dsz == 8)
+        rk = ROWS_F32_F64;
+    else
+        return false;
+    const uint64_t rw = (uint64_t)j.src.src_stride * ssz / 4, nw = (uint64_t)j.M * dsz / 4;
+    const bool dense = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
+    if (!dense && ((rw != 1 && rw != 2 && rw != 3 && rw != 4 && rw != 6 && rw != 8) || nw > ROWS_MAX_WORDS))
+        return false;
+    if ((((uintptr_t)j.dst | (uintptr_t)j.src.src) & 15) != 0)
+        return false;
+    // gathers (tag order through a permutation) stay with the LDS-tiled kernel: one random 16-byte row per
+    // lane costs a whole line either way, and its four-deep row fetches measured faster (417 vs 480-510 us
+    // for two float4 arrays of 10 M rows)
+    if (j.src.order != nullptr && !getenv("PGSD_PACK_ROWS_GATHER"))
+        return false;
+    if (N >= (1ull << 31)) // one lane per row (or per U rows): keeps the grid's x extent below 2^32 threads
+        return false;
+    *kind_out = rk;
+    return true;
+    }
 
 int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err,
                 hipEvent_t ev_start, hipEvent_t ev_stop)
     {
-    std::vector<PendingLaunch> pending;
-    bool generic_used = false;
     if (n_jobs == 0 || N == 0)
         return PGSD_SUCCESS;
     for (uint32_t i = 0; i < n_jobs; i++)
@@ -1032,11 +1344,105 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                 *err = "invalid pack job (types, columns or pointers)";
             return PGSD_ERROR_INVALID_ARGUMENT;
             }
-
+    // every kernel of the call, in issue order; the first one stamps ev_start, the last one ev_stop
+    // (hipExtLaunchKernelGGL: the dispatch's own begin / end times, what rocprofv3 reports)
+    std::vector<std::function<void(hipEvent_t, hipEvent_t)>> launches;
     std::vector<bool> done(n_jobs, false);
-    // jobs the tiled kernel cannot take go through the generic kernel
+
+    // kernel choice (defaults from measurements on MI355X, profiles/; env overrides are for the
+    // tuning sweeps of tools/pack_bench.py)
+    enum
+        {
+        K_ROWS,
+        K_TILES,
+        K_WAVES
+        } kernel
+        = K_ROWS;
+    if (const char* e = getenv("PGSD_PACK_KERNEL"))
+        kernel = strcmp(e, "waves") == 0 ? K_WAVES : (strcmp(e, "tiles") == 0 ? K_TILES : K_ROWS);
+
+    // 1. the row-per-lane kernels take every job they can: one launch per class of source arrays
+    //    (dense copies | rows of rw dwords), up to PACK_MAX_GROUPS arrays each
+    if (kernel == K_ROWS)
+        {
+        while (true)
+            {
+            RowsArgs a;
+            memset(&a, 0, sizeof(a));
+            a.N = N;
+            bool copy = false, bits_only = true;
+            uint32_t cls_rw = 0;
+            for (uint32_t i = 0; i < n_jobs; i++)
+                {
+                if (done[i])
+                    continue;
+                const pgsd_pack_job& j = jobs[i];
+                uint32_t rk = 0;
+                if (!rows_eligible(j, N, &rk))
+                    continue;
+                const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type), dsz = (uint32_t)sizeof_type(j.dst_type);
+                const uint32_t rw = j.src.src_stride * ssz / 4;
+                const bool dense
+                    = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
+                if (a.n_groups == 0)
+                    {
+                    copy = dense;
+                    cls_rw = rw;
+                    }
+                else if (dense != copy || (!dense && rw != cls_rw))
+                    continue; // another class: a later launch
+                int gi = -1;
+                if (!dense)
+                    for (uint32_t k = 0; k < a.n_groups; k++)
+                        if (a.g[k].src == j.src.src && a.g[k].order == j.src.order && a.g[k].n_out < PACK_MAX_OUT)
+                            gi = (int)k;
+                if (gi < 0)
+                    {
+                    if (a.n_groups == PACK_MAX_GROUPS)
+                        continue; // next launch
+                    gi = (int)a.n_groups++;
+                    RowsGroup& g = a.g[gi];
+                    g.src = j.src.src;
+                    g.order = j.src.order;
+                    g.row_words = rw;
+                    if (dense)
+                        {
+                        const uint64_t bytes = N * (uint64_t)j.src.src_stride * ssz;
+                        g.copy_vecs = bytes >> 4;
+                        g.copy_tail = (uint32_t)(bytes & 15);
+                        }
+                    }
+                RowsGroup& g = a.g[gi];
+                RowsOut& o = g.out[g.n_out++];
+                o.dst = j.dst;
+                o.col0 = j.src.src_col0 * ssz / 4; // first source dword
+                o.M = j.M;
+                o.kind = rk;
+                o.nw_out = j.M * dsz / 4;
+                bits_only = bits_only && rk == ROWS_BITS;
+                done[i] = true;
+                }
+            if (a.n_groups == 0)
+                break;
+            const RowsCfg cfg = rows_config(N, a.n_groups);
+            const uint64_t per_block = (uint64_t)cfg.T * cfg.U;
+            uint64_t blocks = 1;
+            for (uint32_t k = 0; k < a.n_groups; k++)
+                {
+                const uint64_t units = copy ? a.g[k].copy_vecs : N;
+                blocks = std::max(blocks, (units + per_block - 1) / per_block);
+                }
+            a.n_blocks = blocks; // N < 2^40 rows (rows_eligible) keeps this below 2^31
+            launches.push_back([=](hipEvent_t e0, hipEvent_t e1)
+                               { launch_rows(cfg, a, copy, cls_rw, bits_only, stream, e0, e1); });
+            }
+        }
+
+    // 2. jobs the tiled kernel cannot take either go through the generic kernel
     for (uint32_t i = 0; i < n_jobs; i++)
         {
+        if (done[i])
+            continue;
         const pgsd_pack_job& j = jobs[i];
         const size_t ssz = sizeof_type(j.src.src_type);
         const uint64_t rowbytes = (uint64_t)j.src.src_stride * ssz;
@@ -1060,17 +1466,21 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t cap = (uint64_t)num_cus() * 8;
             if (blocks > cap)
                 blocks = cap;
-            if (!generic_used && ev_start)
-                (void)hipEventRecord(ev_start, stream); // mixed launches: bracket them all
-            generic_used = true;
-            hipLaunchKernelGGL(pack_generic_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), 0, stream, a);
+            launches.push_back(
+                [a, blocks, stream](hipEvent_t e0, hipEvent_t e1)
+                {
+                    hipExtLaunchKernelGGL(pack_generic_kernel, dim3((unsigned)blocks), dim3(PACK_THREADS), 0, stream, e0, e1,
+                                          0, a);
+                });
             done[i] = true;
             }
         }
 
-    // group the remaining jobs by source array and launch in batches that fit PackArgs
+    // 3. the LDS-tiled kernel: group the remaining jobs by source array, in batches that fit PackArgs
     uint32_t next = 0;
-    while (true)
+    while (next < n_jobs && done[next])
+        next++;
+    while (next < n_jobs)
         {
         PackArgs args;
         memset(&args, 0, sizeof(args));
@@ -1126,14 +1536,10 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         if (!any)
             break;
-        // kernel choice (defaults from measurements on MI355X, profiles/; env overrides are
-        // for the tuning sweeps of tools/pack_bench.py)
-        bool use_waves = false;
+        bool use_waves = kernel == K_WAVES;
         uint64_t per_cu = 4;
         int var = 0;
         uint32_t tile_cap = 1024;
-        if (const char* e = getenv("PGSD_PACK_KERNEL"))
-            use_waves = strcmp(e, "waves") == 0;
         if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
             per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
         if (const char* e = getenv("PGSD_PACK_VARIANT"))
@@ -1159,11 +1565,13 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             uint64_t max_blocks = (N + 255) / 256;
             if (blocks > max_blocks)
                 blocks = max_blocks;
-            pending.push_back({true, false, mode, var, (unsigned)blocks, (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED, args});
+            const size_t lds_bytes = (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED;
+            launches.push_back(
+                [=](hipEvent_t e0, hipEvent_t e1)
+                { launch_variant(true, false, mode, var, (unsigned)blocks, lds_bytes, stream, args, e0, e1); });
             }
         else
             {
-            // tile: as many rows as the widest source row allows, power of two in [16, tile_cap]
             size_t lds_budget = PACK_LDS_BYTES;
             if (const char* e = getenv("PGSD_PACK_LDS_KB"))
                 lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
@@ -1174,7 +1582,6 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                 tile <<= 1;
             args.tile_rows = tile;
             args.n_tiles = (N + tile - 1) / tile;
-            // batches: consecutive groups whose tiles fit the LDS budget together
             size_t lds_bytes = 0, used = 0;
             args.n_batches = 0;
             args.batch_start[0] = 0;
@@ -1213,26 +1620,15 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                 want = atoi(e);
             if (want == 0 || (want < 0 && args.n_tiles > 2 * blocks))
                 prefetch = false;
-            pending.push_back({false, prefetch, mode, var, (unsigned)blocks, lds_bytes, args});
+            launches.push_back(
+                [=](hipEvent_t e0, hipEvent_t e1)
+                { launch_variant(false, prefetch, mode, var, (unsigned)blocks, lds_bytes, stream, args, e0, e1); });
             }
         while (next < n_jobs && done[next])
             next++;
-        if (next == n_jobs)
-            break;
         }
-    for (size_t i = 0; i < pending.size(); i++)
-        {
-        const PendingLaunch& L = pending[i];
-        hipEvent_t s0 = (!generic_used && i == 0) ? ev_start : nullptr;
-        hipEvent_t s1 = (!generic_used && i + 1 == pending.size()) ? ev_stop : nullptr;
-        launch_variant(L.waves, L.prefetch, L.mode, L.var, L.blocks, L.lds_bytes, stream, L.args, s0, s1);
-        }
-    if (ev_stop && (generic_used || pending.empty()))
-        {
-        if (!generic_used && ev_start)
-            (void)hipEventRecord(ev_start, stream);
-        (void)hipEventRecord(ev_stop, stream);
-        }
+    for (size_t i = 0; i < launches.size(); i++)
+        launches[i](i == 0 ? ev_start : nullptr, i + 1 == launches.size() ? ev_stop : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         {

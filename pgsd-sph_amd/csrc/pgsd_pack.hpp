@@ -80,6 +80,45 @@ struct PackArgs
     PackGroup g[PACK_MAX_GROUPS];
     };
 
+// ---- row-per-lane kernel (pack_rows_kernel): the default for 4- and 8-byte elements
+enum
+    {
+    ROWS_MAX_WORDS = 8, // a source row / a chunk row is at most 8 dwords (double4, N x 4 doubles)
+    ROWS_BITS = 0,      // dwords moved unchanged (equal element sizes; 8-byte elements are dword pairs)
+    ROWS_F64_F32 = 1,   // f64 -> f32, round to nearest even
+    ROWS_F32_F64 = 2    // f32 -> f64
+    };
+
+struct RowsOut
+    {
+    void* dst;       // chunk buffer
+    uint32_t col0;   // first source ELEMENT (not dword)
+    uint32_t M;      // chunk columns
+    uint32_t kind;   // ROWS_*
+    uint32_t nw_out; // dwords per chunk row = M * dsz / 4
+    };
+
+struct RowsGroup
+    {
+    const void* src;
+    const uint32_t* order; // gather index or nullptr
+    uint64_t copy_vecs;    // dense same-type copy: 16-byte vectors to move (0 = row mode)
+    uint32_t copy_tail;    // ... and bytes behind the last whole vector
+    uint32_t row_words;    // dwords per source row
+    uint32_t n_out;
+    uint32_t pad;
+    RowsOut out[PACK_MAX_OUT];
+    };
+
+struct RowsArgs
+    {
+    uint64_t N;
+    uint64_t n_blocks;     // gridDim.x: blocks of T*U rows (or 16-byte vectors); gridDim.y = n_groups
+    uint32_t n_groups;
+    uint32_t pad;
+    RowsGroup g[PACK_MAX_GROUPS];
+    };
+
 struct PackGenericArgs
     {
     void* dst;

@@ -61,20 +61,22 @@ class ConfigurationData(object):
         self.dimensions = None
         self._box = None
 
-    @property
-    def box(self):
+    def _get_box(self):
         return self._box
 
-    @box.setter
-    def box(self, box):
-        self._box = box
+    def _set_box(self, value):
+        # setting a box also fixes `dimensions` while the user has not chosen one: 2 for a flat box
+        # (Lz == 0), else 3 (hoomd.py:89-99)
+        self._box = value
+        if self.dimensions is not None:
+            return
         try:
-            Lz = box[2]
+            flat = value[2] == 0
         except TypeError:
             return
-        else:
-            if self.dimensions is None:
-                self.dimensions = 2 if Lz == 0 else 3
+        self.dimensions = 2 if flat else 3
+
+    box = property(_get_box, _set_box)
 
     def validate(self):
         """Convert ``box`` to a (6,) float32 array; ignore attributes that are ``None``."""
@@ -216,43 +218,26 @@ class Frame(object):
         self.constraints.validate()
 
 
-class _HOOMDTrajectoryIterable(object):
-    """Iterable over a HOOMDTrajectory object."""
-
-    def __init__(self, trajectory, indices):
-        self._trajectory = trajectory
-        self._indices = indices
-        self._indices_iterator = iter(indices)
-
-    def __next__(self):
-        return self._trajectory[next(self._indices_iterator)]
-
-    next = __next__
-
-    def __iter__(self):
-        return type(self)(self._trajectory, self._indices)
-
-    def __len__(self):
-        return len(self._indices)
-
-
-class _HOOMDTrajectoryView(object):
-    """A view of a HOOMDTrajectory object (slicing / iteration over a subset)."""
+class _FrameSubset(object):
+    """The frames of a trajectory picked by a sequence of indices: what slicing a
+    `HOOMDTrajectory` returns (the role of hoomd.py:470-512).  Supports ``len``, iteration,
+    integer indexing and further slicing; frames are read when they are asked for."""
 
     def __init__(self, trajectory, indices):
         self._trajectory = trajectory
         self._indices = indices
 
-    def __iter__(self):
-        return _HOOMDTrajectoryIterable(self._trajectory, self._indices)
-
     def __len__(self):
         return len(self._indices)
+
+    def __iter__(self):
+        return (self._trajectory[i] for i in self._indices)
 
     def __getitem__(self, key):
+        picked = self._indices[key]
         if isinstance(key, slice):
-            return type(self)(self._trajectory, self._indices[key])
-        return self._trajectory[self._indices[key]]
+            return _FrameSubset(self._trajectory, picked)
+        return self._trajectory[picked]
 
 
 def _encode_strings(strings):
@@ -303,10 +288,32 @@ class HOOMDTrajectory(object):
         ``trajectory.file.wait_packed()`` before changing GPU-resident arrays of the frame and
         ``trajectory.file.frame_sync()`` before relying on the file.
 
-        Fields that are ``None`` are not written.  Host fields that equal the initial frame or
-        the default value are elided exactly as upstream GSD does (hoomd.py:654-694); ranks
-        agree on each decision (a chunk is written if any rank needs it).  GPU-resident fields
-        are always written.
+        The calls this makes are the ones the reference sketches (hoomd.py:569-642), pinned byte for
+        byte against the oracle by ``tests/test_hoomd_append_oracle.py``:
+
+        * order: ``configuration/{step, dimensions, box}``, then ``particles/*`` and ``constraints/*``
+          in the order of their ``_default_value`` tables (hoomd.py:60-63, 167-184), then ``state/*``,
+          then ``log/*``, then ``end_frame``;
+        * ``box``, ``N`` (uint32, ``part_dist.sum()``), ``step`` (uint64), ``dimensions`` (uint8),
+          ``types`` and ``type_shapes`` (int8 ``n x wid``, NUL padded, JSON for the shapes) are
+          replicated small chunks: ``write_all=False, offset=None`` (hoomd.py:604-630);
+        * per-particle arrays: ``write_all=True, offset=part_dist`` (hoomd.py:597-600);
+        * ``state/*`` and ``log/*``: ``write_chunk(name, data)`` with default arguments (hoomd.py:634-640);
+        * fields that are ``None`` are not written; host fields that equal the initial frame or the
+          default value are elided as hoomd.py:654-694 describes.
+
+        Where the sketch cannot be followed literally:
+
+        * ``constraints/*`` are replicated small chunks and ``constraints/N`` is the constraint count
+          (the sketch would write the PARTICLE count as ``constraints/N`` and partition ``value`` /
+          ``group`` by the particle distribution, hoomd.py:597-611: files its own reader rejects);
+        * the write/skip decision of every chunk is agreed over the ranks (written if any rank needs
+          it; a rank without a value contributes the default for its rows), because a chunk write is
+          collective; ``particles/N`` is compared as the global count;
+        * GPU-resident fields are always written (comparing them would cost a device pass and a sync)
+          and all of a frame's consecutive device fields go out in one fused pack launch;
+        * upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom) follow the
+          SPH set in that order when they are set.
         """
         logger.debug('Appending frame to hoomd trajectory: ' + str(self.file))
         frame.validate()
@@ -386,14 +393,14 @@ class HOOMDTrajectory(object):
             self.file.write_chunk(chunk, data, None, rank, False)
         self._flush_device_fields(device_fields, part_dist, rank)
 
-        # state data: what the reference's writer sketches and leaves commented out
-        # (hoomd.py:634-636, upstream GSD's ``state/*`` chunks); replicated like the log
+        # state and logged quantities: the sketch calls ``write_chunk(name, data)`` with the binding's
+        # default arguments (hoomd.py:634-640; the state loop is commented out twice, upstream GSD
+        # has it) -- write_all=True, no offset: every rank writes its (replicated) value at the same
+        # place and the file advances by the ranks' sizes summed (pgsd.c:2240-2246)
         for state, data in frame.state.items():
-            self.file.write_chunk('state/' + state, numpy.ascontiguousarray(data), None, rank, False)
-
-        # logged quantities are replicated
+            self.file.write_chunk('state/' + state, numpy.ascontiguousarray(data))
         for log, data in frame.log.items():
-            self.file.write_chunk('log/' + log, data, None, rank, False)
+            self.file.write_chunk('log/' + log, data)
 
         self.file.end_frame(wait=wait)
 
@@ -654,21 +661,22 @@ class HOOMDTrajectory(object):
             setattr(container, attr, container._default_value[attr])
 
     def __getitem__(self, key):
-        """Index trajectory frames (int, negative int or slice, like a list)."""
+        """``trajectory[i]`` reads one frame (negative ``i`` counts from the end), ``trajectory[a:b:c]``
+        returns a lazy subset."""
+        n = len(self)
         if isinstance(key, slice):
-            return _HOOMDTrajectoryView(self, range(*key.indices(len(self))))
-        elif isinstance(key, (int, numpy.integer)):
-            key = int(key)
-            if key < 0:
-                key += len(self)
-            if key >= len(self) or key < 0:
-                raise IndexError()
-            return self._read_frame(key)
-        else:
+            return _FrameSubset(self, range(*key.indices(n)))
+        if not isinstance(key, (int, numpy.integer)):
             raise TypeError
+        idx = int(key)
+        if idx < 0:
+            idx += n
+        if not 0 <= idx < n:
+            raise IndexError()
+        return self._read_frame(idx)
 
     def __iter__(self):
-        return _HOOMDTrajectoryIterable(self, range(len(self)))
+        return iter(_FrameSubset(self, range(len(self))))
 
     def __enter__(self):
         return self

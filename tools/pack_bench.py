@@ -94,6 +94,9 @@ def make_jobs(workload, N, gen):
     return jobs, algo, moved, keep
 
 
+AB_KEYS = ("PGSD_PACK_VARIANT", "PGSD_PACK_KERNEL", "PGSD_PACK_ROWS_CFG", "PGSD_PACK_TILE", "PGSD_PACK_BLOCKS_PER_CU")
+
+
 def to_c(jobs):
     arr = (_lib.PackJob * len(jobs))()
     for i, (dst, out_dt, M, src, col0, order, bitcast) in enumerate(jobs):
@@ -132,7 +135,16 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
             torch.cuda.synchronize()
             time.sleep(sleep_ms * 1e-3)   # let the GPU idle between launches, like a snapshot every few ms
         if variants:
-            os.environ["PGSD_PACK_VARIANT"] = variants[i % len(variants)]   # interleaved A/B in one process
+            # interleaved A/B in one process: "3" = PGSD_PACK_VARIANT=3, "K=V+K2=V2" = those variables
+            v = variants[i % len(variants)]
+            for k in AB_KEYS:
+                os.environ.pop(k, None)
+            if "=" in v:
+                for kv in v.split("+"):
+                    k, _, val = kv.partition("=")
+                    os.environ[k] = val
+            else:
+                os.environ["PGSD_PACK_VARIANT"] = v
         evs[i][0].record()
         _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
         evs[i][1].record()
@@ -157,7 +169,8 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sleep-ms", type=float, default=0.0)
-    ap.add_argument("--variants", default="", help="comma list of PGSD_PACK_VARIANT values to interleave")
+    ap.add_argument("--variants", default="", help="comma list of variants to interleave launch by launch: a "
+                    "PGSD_PACK_VARIANT value, or KEY=VALUE[+KEY=VALUE] settings of the PGSD_PACK_* variables")
     a = ap.parse_args()
     for w in a.workloads.split(","):
         r = run(w, a.N, a.iters, a.warmup, a.sleep_ms, [v for v in a.variants.split(',') if v] or None)
