@@ -2,9 +2,10 @@
 """bench.py -- snapshot pack+write throughput of the MI355X-native PGSD writer.
 
 One "step" = one frame of the hot path on one batch of synthetic particle data that is
-already resident in HBM: RCCL allgather of the per-rank row counts (file offsets), fused
-HIP pack of position / velocity / typeid from HOOMD-style float4 arrays, hipMemcpyAsync to
-pinned slabs, pwrite into one shared GSD file on tmpfs, index commit (pgsd_end_frame).
+already resident in HBM: fused HIP pack of position / velocity / typeid from HOOMD-style float4
+arrays, ONE allgather of the ranks' chunk sizes (RCCL over xGMI for N > 1; gives every rank's row
+count -> file offsets) in flight while the kernel runs, hipMemcpyAsync to pinned slabs, pwrite
+into one shared GSD file on tmpfs, index commit (pgsd_end_frame).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -99,6 +100,86 @@ def cpu_baseline(n_particles, frames, out_dir):
                       "reference write sequence, 1 thread, file on %s" % (frames, n_particles, out_dir)}
 
 
+PACK_KERNEL = "pack_rows_kernel"   # the dominant kernel of the default layout (pgsd_pack.hip); dense scalar
+                                   # arrays of the full schemas additionally go through pack_copy_kernel
+
+
+def pack_source_sha256():
+    import hashlib
+    with open(os.path.join(ROOT, "pgsd-sph_amd", "csrc", "pgsd_pack.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_pass(counter, child_args, timeout):
+    """One rocprofv3 counter pass over a short child run of this script; returns
+    {kernel name: [value per dispatch]} for the pack kernels, or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="pgsd_pmc_", dir="/tmp")
+    try:
+        # the program itself follows `--` (no env/bash hop: the profiler's library has the GPU initialised)
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__)] + child_args
+        r = subprocess.run(cmd, timeout=timeout, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        if r.returncode != 0:
+            return None
+        out = {}
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    name = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == counter and ("pgsd_amd::pack_" in name):
+                        out.setdefault(name, []).append(float(row["Counter_Value"]))
+        return out or None
+    except Exception as e:  # time-out, unreadable output, ...
+        print("bench.py: %s pass failed (%s)" % (counter, e), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_traffic_live(args):
+    """-> (HBM bytes per frame's pack launch(es), source text, detail) from two PMC passes, or Nones."""
+    child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--particles", str(args.particles), "--schema", args.schema,
+             "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test"]
+    if args.separate_id:
+        child.append("--separate-id")
+    fetch = pmc_pass("FETCH_SIZE", child, 240)
+    write = pmc_pass("WRITE_SIZE", child, 240) if fetch else None
+    if not fetch or not write:
+        return None, None, None
+    import statistics
+    # per frame: the median dispatch of every pack kernel of a frame, summed over the kernels
+    fetch_kib = sum(statistics.median(v) for v in fetch.values())
+    write_kib = sum(statistics.median(v) for v in write.values())
+    read_bytes = int(fetch_kib * 1024 * 2)     # gfx950: FETCH_SIZE counts half of a wide coalesced read stream
+    write_bytes = int(write_kib * 1024)
+    detail = {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "read_bytes": read_bytes,
+              "write_bytes": write_bytes, "kernels": sorted(fetch),
+              "corrections": "bytes = KiB*1024; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)"}
+    return read_bytes + write_bytes, "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this run", detail
+
+
+def traffic_from_file(N, args):
+    """The committed PMC result, only while it describes the kernel source that is being run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pack_traffic.json")) as tf:
+            tj = json.load(tf)
+        if tj.get("particles") == N and args.schema == "pvi" and not args.separate_id:
+            if tj.get("pack_source_sha256") != pack_source_sha256():
+                return None, "profiles/pack_traffic.json is older than pgsd_pack.hip: not reported"
+            return tj["hbm_bytes_per_launch"], "file: profiles/pack_traffic.json (" + tj.get("source", "") + ")"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +188,7 @@ def main():
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--dir", default=os.environ.get("PGSD_BENCH_DIR", "/dev/shm"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stall-test", action="store_true", help="skip the asynchronous-sealing stall measurement")
     ap.add_argument("--slab-mib", type=int, default=0)
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
@@ -118,6 +200,10 @@ def main():
     ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
                     help="N>1: auto = the library's own RCCL communicator, torch.distributed callbacks if it cannot be "
                          "built; rccl = no fallback; torch = callbacks only")
+    ap.add_argument("--traffic", choices=["live", "file", "off"], default="live",
+                    help="roofline.traffic (HBM bytes of one pack launch from the PMC counters): live = two child runs "
+                         "of this script under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; N=1 "
+                         "only), falling back to file = profiles/pack_traffic.json when that is not possible")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -222,11 +308,16 @@ def main():
     f.configure_device(device=local_rank, slab_bytes=args.slab_mib << 20, n_slabs=args.slabs,
                        n_writers=args.writers, profile=True)
 
+    # ONE collective per frame (pgsd_set_frame_exchange): the replicated step chunk and the fused device
+    # chunks are queued -- the pack kernel is launched at once, it needs no file offset -- and end_frame's
+    # single allgather (one ncclAllGather over xGMI on the RCCL back end, in flight while the kernel runs)
+    # carries every rank's chunk sizes, from which each rank derives N_global, its first row and all file
+    # offsets (offset="auto": the MPI_Allgather of benchmark-write.cc:39-45 is inside that exchange).
+    f.frame_exchange = True
+
     def step(i):
-        # per-rank file offsets: allgather of the local row counts (RCCL over xGMI for N > 1)
-        counts, row0, n_global = pdist.partition_rows(N)
         f.write_chunk("configuration/step", np.array([i], dtype=np.uint64), write_all=False)
-        f.write_chunks(fields, offset=counts, rank=rank)
+        f.write_chunks(fields, offset="auto")
         f.end_frame()
 
     def fence():
@@ -238,25 +329,26 @@ def main():
         step(i)
     f.device_stats(reset=True)
     fence()
+    coll0 = f.collective_count
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     stats = f.device_stats()
+    collectives_per_frame = (f.collective_count - coll0) / max(args.steps, 1)
 
     # What a simulation is blocked for per snapshot when it seals frames asynchronously: issue the
     # frame, wait for the pack kernels only (the arrays may then change), let copy + write run on.
     stall_ms = None
-    if world == 1:
+    if world == 1 and not args.no_stall_test:
         stalls = []
         for i in range(3):
             f.frame_sync()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            counts, row0, n_global = pdist.partition_rows(N)
             f.write_chunk("configuration/step", np.array([10 ** 6 + i], dtype=np.uint64), write_all=False)
-            f.write_chunks(fields, offset=counts, rank=rank)
+            f.write_chunks(fields, offset="auto")
             f.end_frame(wait=False)
             f.wait_packed()
             stalls.append((time.perf_counter() - t1) * 1e3)
@@ -287,16 +379,13 @@ def main():
             dist.destroy_process_group()
         return
 
-    # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this
-    # process); only reported when it was measured for this particle count
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pack_traffic.json")) as tf:
-            tj = json.load(tf)
-        if tj.get("particles") == N and args.schema == "pvi" and not args.separate_id:
-            traffic = tj["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes of one pack launch from the PMC counters (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and
+    # WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950 for wide coalesced reads)
+    traffic, traffic_source, traffic_detail = None, None, None
+    if args.traffic == "live" and world == 1:
+        traffic, traffic_source, traffic_detail = measure_traffic_live(args)
+    if traffic is None and args.traffic != "off":
+        traffic, traffic_source = traffic_from_file(N, args)
 
     total_bytes = world * args.steps * N * payload_bpp
     value = total_bytes / dt / 1e9
@@ -315,13 +404,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%d particles/GPU, position+velocity+typeid packed from %s, "
-                               "%s allgather of row counts, one shared GSD file on %s"
+                               "%s allgather of chunk sizes (one per frame), one shared GSD file on %s"
                                % (N, layout, comm_backend, args.dir),
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
+        "comm_backend": comm_backend,
+        "collectives_per_frame": collectives_per_frame,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "pack_tiles_kernel", "avg_ms": round(pack_ms, 5),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_detail": traffic_detail,
+                     "kernel": PACK_KERNEL, "avg_ms": round(pack_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bpp * N},
         "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
                            "note": "sum over ranks of the pack kernel rate (independent kernels, one per GPU)"},

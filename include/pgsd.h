@@ -194,6 +194,39 @@ extern "C"
                          uint8_t flags,
                          const void* data);
 
+    /* N_global == PGSD_PARTITION_AUTO (pgsd_write_chunk, pgsd_write_chunk_device, pgsd_write_chunks_device):
+       the chunk is partitioned over the ranks in rank order and the library derives the global row
+       count and this rank's first row (`offset` / `offset_rows` are then ignored) from the size exchange
+       the chunk write performs anyway -- the caller-side MPI_Allgather of the reference's callers
+       (benchmark-write.cc:39-45, fl.pyx:596-598) is not needed. */
+#define PGSD_PARTITION_AUTO UINT64_MAX
+
+    /* Frame-batched exchange (off after open).
+       Off: every chunk write exchanges the ranks' sizes at once -- the reference's per-chunk Allreduces
+       (pgsd.c:2157, 2242) as one 16-byte allgather -- so handle->file_size is current after each call,
+       and pgsd_end_frame ends with a status exchange that doubles as the barrier after which every
+       rank's rows of the frame are in the file.
+       On: chunk writes that do not need their file offset at once are QUEUED: replicated chunks below
+       the write-buffer limit (copied) and all device chunks (packed into the staging arena at once,
+       the kernel needs no offset).  ONE allgather at the next pgsd_end_frame (or pgsd_flush,
+       pgsd_close, a read, a host per-particle chunk, a buffer-limit setter) carries every rank's
+       status word and the byte counts of all queued chunks; placement then replays the reference's
+       decisions in call order, so the file is byte-identical to the unbatched one.  A frame of
+       small chunks + device chunks + pgsd_end_frame costs ONE collective (one ncclAllGather on the
+       RCCL back end, issued after the pack launch and overlapping it).  Consequences: the handle's
+       file_size / pending_index_entries mirror lags until the queue is resolved; a failure on one
+       rank is returned there at once and reaches the others with the next exchange; the barrier
+       covering a sealed frame is made up at the next pgsd_flush / pgsd_close / read or by the next
+       frame's exchange.  Collective like pgsd_end_frame when it turns batching off. */
+    int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched);
+    int pgsd_get_frame_exchange(struct pgsd_handle* handle);
+    /* Perform the exchange now (collective; nothing is flushed): afterwards the queue is empty and the
+       handle's mirror is current.  No-op when nothing is queued. */
+    int pgsd_frame_exchange(struct pgsd_handle* handle);
+    /* Number of collectives (allgathers, barriers) this handle has issued on its communicator since it
+       was opened: the evidence behind "one collective per frame" (bench.py, tests). */
+    uint64_t pgsd_get_collective_count(struct pgsd_handle* handle);
+
     /* reference pgsd.h:581-582 */
     const struct pgsd_index_entry*
     pgsd_find_chunk(struct pgsd_handle* handle, uint64_t frame, const char* name);
@@ -387,6 +420,11 @@ extern "C"
         struct pgsd_field_desc src;
         };
     int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream);
+    /* The same, timed: *kernel_ms receives the time from the begin of the first to the end of the last
+       kernel of the call as the dispatches themselves stamp it (what rocprofv3 reports per kernel; no
+       launch latency).  Synchronises `stream`.  Measurement only (tools/pack_bench.py). */
+    int pgsd_pack_fields_timed(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream,
+                               float* kernel_ms);
 
     /* Stream compaction for filtered snapshots: out_index[k] = i for the k-th row whose
        flag byte is non-zero (stable), *out_count (device uint64) = number selected.

@@ -95,11 +95,20 @@ static pgsd_comm make_self()
     return c;
     }
 
-static pgsd_comm g_comm = make_self();
+static std::shared_ptr<CommBox>& comm_slot()
+    {
+    static std::shared_ptr<CommBox> box = std::make_shared<CommBox>(make_self());
+    return box;
+    }
+
+std::shared_ptr<CommBox> default_comm_box()
+    {
+    return comm_slot();
+    }
 
 pgsd_comm default_comm()
     {
-    return g_comm;
+    return comm_slot()->c;
     }
 
 // ---------------------------------------------------------------- shm
@@ -233,20 +242,21 @@ static int shm_allgather(void* p, const void* send, void* recv, size_t bytes)
 static void shm_destroy(void* p)
     {
     ShmCtx* c = (ShmCtx*)p;
-    // everyone is past its last use before rank 0 removes the name
+    // Rank 0 removes the NAME first (the mapping outlives it), then everyone meets once more: a rank
+    // that comes out of this barrier and re-initialises under the same name can no longer open the
+    // old segment.
+    if (c->rank == 0)
+        shm_unlink(c->name.c_str());
     (void)shm_barrier(p);
     __atomic_store_n(&c->seg->pids[c->rank], 0, __ATOMIC_RELEASE); // leaving in good order
     munmap((void*)c->seg, c->map_bytes);
-    if (c->rank == 0)
-        shm_unlink(c->name.c_str());
     delete c;
     }
 
 static int comm_install(const pgsd_comm& c)
     {
-    if (g_comm.destroy)
-        g_comm.destroy(g_comm.ctx);
-    g_comm = c;
+    // the previous communicator is destroyed here unless open handles still hold it
+    comm_slot() = std::make_shared<CommBox>(c);
     return PGSD_SUCCESS;
     }
     } // namespace pgsd_amd
@@ -298,7 +308,33 @@ static int shm_attach(const char* name, int rank, int size, int attempt)
     int fd = -1;
     if (rank == 0)
         {
-        shm_unlink(nm.c_str()); // stale segment of a crashed run
+        // a segment of that name left by a crashed run is removed; one whose creator is another LIVE
+        // process belongs to a running job (two jobs of one user picked the same name) and is left alone
+        int old = shm_open(nm.c_str(), O_RDWR, 0600);
+        if (old >= 0)
+            {
+            struct stat st;
+            int32_t creator = 0;
+            if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(ShmSegment))
+                {
+                void* om = mmap(NULL, sizeof(ShmSegment), PROT_READ, MAP_SHARED, old, 0);
+                if (om != MAP_FAILED)
+                    {
+                    const ShmSegment* os = (const ShmSegment*)om;
+                    if (os->ready == SHM_MAGIC)
+                        creator = os->creator_pid;
+                    munmap(om, sizeof(ShmSegment));
+                    }
+                }
+            close(old);
+            if (creator > 0 && creator != (int32_t)getpid() && !process_gone(creator))
+                {
+                set_last_error("shm segment " + nm + " is in use by live process " + std::to_string(creator)
+                               + ": choose another PGSD_SHM_NAME");
+                return PGSD_ERROR_COMM;
+                }
+            shm_unlink(nm.c_str());
+            }
         fd = shm_open(nm.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
         if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0)
             {
@@ -427,7 +463,8 @@ extern "C" int pgsd_comm_init_from_env(void)
     const char* nm = getenv("PGSD_SHM_NAME");
     if (r && n)
         {
-        std::string name = nm ? nm : "pgsd_amd_default";
+        // ranks started by one launcher share their parent: a name no other job of this user has
+        std::string name = nm ? nm : std::string("pgsd_amd_ppid_") + std::to_string((long)getppid());
         return pgsd_comm_init_shm(name.c_str(), atoi(r), atoi(n));
         }
     r = getenv("RANK");

@@ -4,7 +4,11 @@
 // each rank derives its file offsets (MPI_Allgather in the reference's callers,
 // benchmark-write.cc:41, and in pgsd.c:1126) -- runs as ONE ncclAllGather over the xGMI
 // mesh of the node, on a private HIP stream, between two small device buffers; the
-// host reads the P gathered values back from pinned memory.  Messages are a few bytes,
+// host reads the P gathered values back from pinned memory.  With the frame exchange batched
+// (pgsd_set_frame_exchange) it is also the only collective of a frame, and it is issued after the
+// frame's pack kernel has been enqueued on the pipeline's own stream: the two run side by side, and
+// the host waits for the gathered sizes only where the file offsets are needed (before the copies
+// are handed to the writer).  Messages are a few bytes,
 // so this is latency-bound; what matters is that it is a single device collective that
 // can be ordered against kernels (e.g. a count produced by pgsd_select_rows) without a
 // host round trip through MPI.
@@ -81,17 +85,25 @@ static bool rccl_reserve(RcclCtx* c, size_t bytes)
     if (bytes <= c->cap)
         return true;
     size_t cap = bytes < 256 ? 256 : bytes;
+    // the old buffers go first and the context forgets them at once: a failed allocation below must not
+    // leave a capacity that points at freed memory
     if (c->d_send)
-        {
         (void)hipFree(c->d_send);
+    if (c->d_recv)
         (void)hipFree(c->d_recv);
+    if (c->h_send)
         (void)hipHostFree(c->h_send);
+    if (c->h_recv)
         (void)hipHostFree(c->h_recv);
-        }
+    c->d_send = c->d_recv = c->h_send = c->h_recv = nullptr;
+    c->cap = 0;
     if (hipMalloc((void**)&c->d_send, cap) != hipSuccess || hipMalloc((void**)&c->d_recv, cap * (size_t)c->size) != hipSuccess
         || hipHostMalloc((void**)&c->h_send, cap, hipHostMallocDefault) != hipSuccess
         || hipHostMalloc((void**)&c->h_recv, cap * (size_t)c->size, hipHostMallocDefault) != hipSuccess)
+        {
+        set_last_error("RCCL communicator: cannot allocate the exchange buffers");
         return false;
+        }
     c->cap = cap;
     return true;
     }
@@ -127,12 +139,13 @@ static void rccl_destroy(void* p)
     if (c->comm)
         g_rccl.CommDestroy(c->comm);
     if (c->d_send)
-        {
         (void)hipFree(c->d_send);
+    if (c->d_recv)
         (void)hipFree(c->d_recv);
+    if (c->h_send)
         (void)hipHostFree(c->h_send);
+    if (c->h_recv)
         (void)hipHostFree(c->h_recv);
-        }
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;

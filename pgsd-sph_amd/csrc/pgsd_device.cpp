@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <unistd.h>
 #include <cerrno>
@@ -278,7 +279,13 @@ class DevicePipeline
             (void)hipStreamDestroy(m_copy_stream);
         }
 
-    int submit(std::vector<DeviceChunk>& chunks, uint64_t N)
+    // Pack now, place later.  stage() packs the chunks into the staging arena with one fused launch and
+    // returns a ticket; commit() tells where chunk `index` of the ticket goes -- a file offset (asynchronous
+    // copy + pwrite), a host buffer (synchronous copy: small replicated chunks headed for the write
+    // buffer) or nowhere (both absent) -- and the ticket is closed by its last commit.  Between the two
+    // calls lies the frame's size exchange between the ranks: the pack kernel does not need file
+    // offsets, so it runs while the exchange is on its way.
+    int stage(std::vector<DeviceChunk>& chunks, uint64_t N, int* ticket)
         {
         if (!m_ok)
             return PGSD_ERROR_NO_DEVICE;
@@ -336,45 +343,84 @@ class DevicePipeline
         hipEvent_t packed;
         HIP_TRY(hipEventCreateWithFlags(&packed, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(packed, m_pack_stream));
+        std::lock_guard<std::mutex> g(m_mutex);
+        m_misc_events.push_back(packed);
+        m_stats.pack_launches++;
+        m_stats.pack_rows += N;
+        m_stats.pack_bytes_in += bytes_in;
+        m_stats.pack_bytes_out += bytes_out;
+        Staged st;
+        st.chunks = chunks;
+        st.packed = packed;
+        st.open = chunks.size();
+        st.ramped = false;
+        *ticket = m_next_ticket++;
+        m_staged[*ticket] = st;
+        return PGSD_SUCCESS;
+        }
+
+    int commit(int ticket, size_t index, long long file_offset, void* host_dst)
+        {
+        DeviceChunk c;
+        hipEvent_t packed;
+        bool ramp;
             {
             std::lock_guard<std::mutex> g(m_mutex);
-            m_misc_events.push_back(packed);
-            m_stats.pack_launches++;
-            m_stats.pack_rows += N;
-            m_stats.pack_bytes_in += bytes_in;
-            m_stats.pack_bytes_out += bytes_out;
+            auto it = m_staged.find(ticket);
+            if (it == m_staged.end() || index >= it->second.chunks.size())
+                return PGSD_ERROR_INVALID_ARGUMENT;
+            c = it->second.chunks[index];
+            packed = it->second.packed;
+            ramp = !it->second.ramped && !host_dst && file_offset >= 0;
+            if (ramp)
+                it->second.ramped = true; // the first chunk of a launch starts with small pieces
+            if (--it->second.open == 0)
+                m_staged.erase(it);
             }
-
-        bool ramped = false;
-        for (auto& c : chunks)
+        const size_t bytes = (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type));
+        if (bytes == 0 || (!host_dst && file_offset < 0))
+            return PGSD_SUCCESS;
+        if (failed())
+            return PGSD_ERROR_DEVICE;
+        if (host_dst)
             {
-            size_t bytes = (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type));
-            if (c.host_dst)
-                {
-                // small replicated chunk headed for the write buffer: synchronous
-                HIP_TRY(hipStreamSynchronize(m_pack_stream));
-                HIP_TRY(hipMemcpy(c.host_dst, c.job.dst, bytes, hipMemcpyDeviceToHost));
-                }
-            else
-                {
-                CopyJob j;
-                j.dsrc = (const char*)c.job.dst;
-                j.bytes = bytes;
-                j.file_offset = c.file_offset;
-                j.packed = packed;
-                j.ramp = !ramped; // the first chunk of a submit starts with small pieces
-                ramped = true;
-                size_t pieces = 0;
-                for (size_t off = 0; off < bytes; off += piece_len(off, bytes, j.ramp))
-                    pieces++;
-                std::unique_lock<std::mutex> lk(m_mutex);
-                m_outstanding += pieces;
-                m_jobs.push_back(j);
-                lk.unlock();
-                m_cv_jobs.notify_one();
-                }
+            // small replicated chunk headed for the write buffer: synchronous
+            HIP_TRY(hipSetDevice(m_cfg.device));
+            HIP_TRY(hipStreamSynchronize(m_pack_stream));
+            HIP_TRY(hipMemcpy(host_dst, c.job.dst, bytes, hipMemcpyDeviceToHost));
+            return PGSD_SUCCESS;
             }
+        CopyJob j;
+        j.dsrc = (const char*)c.job.dst;
+        j.bytes = bytes;
+        j.file_offset = file_offset;
+        j.packed = packed;
+        j.ramp = ramp;
+        size_t pieces = 0;
+        for (size_t off = 0; off < bytes; off += piece_len(off, bytes, j.ramp))
+            pieces++;
+        std::unique_lock<std::mutex> lk(m_mutex);
+        m_outstanding += pieces;
+        m_jobs.push_back(j);
+        lk.unlock();
+        m_cv_jobs.notify_one();
         return PGSD_SUCCESS;
+        }
+
+    // stage + commit at once: the caller already knows where the chunks go
+    int submit(std::vector<DeviceChunk>& chunks, uint64_t N)
+        {
+        int ticket = -1;
+        int rc = stage(chunks, N, &ticket);
+        for (size_t i = 0; i < chunks.size() && rc == PGSD_SUCCESS; i++)
+            rc = commit(ticket, i, chunks[i].host_dst ? -1 : chunks[i].file_offset, chunks[i].host_dst);
+        return rc;
+        }
+
+    bool staged_open()
+        {
+        std::lock_guard<std::mutex> g(m_mutex);
+        return !m_staged.empty();
         }
 
     // ---- read side: file -> pinned slab (pread) -> HBM staging (H2D) -> unpack kernel ----
@@ -437,7 +483,7 @@ class DevicePipeline
             std::lock_guard<std::mutex> g(m_mutex);
             writes_idle = m_outstanding == 0;
             }
-        if (writes_idle)
+        if (writes_idle && !staged_open())
             {
             release_events();
             for (auto& a : m_arenas)
@@ -484,9 +530,12 @@ class DevicePipeline
         if (e != hipSuccess)
             fail(std::string("stream synchronize: ") + hipGetErrorString(e));
         collect_timings();
-        release_events();
-        for (auto& a : m_arenas)
-            a.used = 0;
+        if (!staged_open())
+            {
+            release_events();
+            for (auto& a : m_arenas)
+                a.used = 0;
+            }
         if (failed())
             {
             // let the writers finish what they hold before the caller tears anything down
@@ -532,6 +581,13 @@ class DevicePipeline
         uint64_t N;
         size_t pieces_left;
         hipEvent_t all_copied;
+        };
+    struct Staged
+        {
+        std::vector<DeviceChunk> chunks;
+        hipEvent_t packed;
+        size_t open;
+        bool ramped;
         };
     struct CopyJob
         {
@@ -595,6 +651,8 @@ class DevicePipeline
         bool idle;
             {
             std::lock_guard<std::mutex> g(m_mutex);
+            if (!m_staged.empty())
+                return PGSD_SUCCESS; // packed chunks still wait for their place in the file
             idle = m_outstanding == 0 && m_reads_outstanding == 0 && m_jobs.empty();
             }
         const size_t soft_cap = (size_t)6 << 30;
@@ -954,6 +1012,8 @@ class DevicePipeline
     std::deque<uint32_t> m_free_slabs;
     std::vector<Arena> m_arenas;
     std::deque<CopyJob> m_jobs;
+    std::map<int, Staged> m_staged; // packed chunks whose file offsets are not known yet
+    int m_next_ticket = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> m_pack_events, m_copy_events;
     std::vector<hipEvent_t> m_misc_events;
     WriterPool* m_pool = nullptr;
@@ -995,6 +1055,23 @@ void device_pipeline_destroy(DevicePipeline* p)
 int device_pipeline_submit(DevicePipeline* p, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err)
     {
     int rc = p->submit(chunks, N);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_stage(DevicePipeline* p, std::vector<DeviceChunk>& chunks, uint64_t N, int* ticket, std::string* err)
+    {
+    int rc = p->stage(chunks, N, ticket);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_commit(DevicePipeline* p, int ticket, size_t index, long long file_offset, void* host_dst,
+                           std::string* err)
+    {
+    int rc = p->commit(ticket, index, file_offset, host_dst);
     if (rc != PGSD_SUCCESS && err)
         *err = p->error();
     return rc;

@@ -141,8 +141,27 @@ static void sort_index(std::vector<pgsd_index_entry>& v)
         }
     }
 
+// A chunk write whose placement waits for the frame's size exchange (pgsd_set_frame_exchange).
+struct Queued
+    {
+    std::string name;
+    uint32_t type = 0;
+    uint64_t N = 0;
+    uint32_t M = 0;
+    uint64_t N_global = 0; // PGSD_PARTITION_AUTO: derived from the exchange, like `offset`
+    uint32_t M_global = 0;
+    uint64_t offset = 0;
+    bool all = false;
+    int local_rc = PGSD_SUCCESS;    // this rank's argument / staging verdict
+    std::vector<char> host;         // copy of a small host chunk
+    const void* borrowed = nullptr; // host rows of the call that is resolving the queue right now
+    int ticket = -1;                // device chunk: packed in the staging arena, waiting for its place
+    size_t ticket_index = 0;
+    };
+
 struct Impl
     {
+    std::shared_ptr<CommBox> comm_box; // keeps the communicator alive for as long as the file is open
     pgsd_comm comm;
     int rank = 0, P = 1;
     int fd = -1;
@@ -172,6 +191,11 @@ struct Impl
     DevicePipeline* dev = nullptr;
     pgsd_device_config devcfg;
     bool devcfg_set = false;
+    // frame-batched exchange: chunk writes that do not need their file offset at once are queued and
+    // ONE allgather per frame (at pgsd_end_frame) carries their sizes and the ranks' status
+    bool batch = false;
+    bool unsynced = false; // a batched frame was sealed that no barrier between the ranks has covered yet
+    std::vector<Queued> queue;
 
     bool v1() const
         {
@@ -192,6 +216,14 @@ struct Impl
         return pool;
         }
 
+    uint64_t n_collectives = 0; // allgathers / barriers this handle has issued (pgsd_get_collective_count)
+
+    int gather(const void* send, void* recv, size_t bytes)
+        {
+        n_collectives++;
+        return comm.allgather(comm.ctx, send, recv, bytes);
+        }
+
     int allgather_u64(uint64_t v, std::vector<uint64_t>& out)
         {
         out.assign((size_t)P, 0);
@@ -200,7 +232,7 @@ struct Impl
             out[0] = v;
             return PGSD_SUCCESS;
             }
-        if (comm.allgather(comm.ctx, &v, out.data(), sizeof(uint64_t)) != 0)
+        if (gather(&v, out.data(), sizeof(uint64_t)) != 0)
             {
             set_last_error("communicator allgather failed");
             return PGSD_ERROR_COMM;
@@ -243,7 +275,7 @@ static int agree_status(Impl* s, int local_rc)
         return local_rc;
     int32_t mine[2] = {local_rc, local_rc ? errno : 0};
     std::vector<int32_t> all((size_t)s->P * 2);
-    if (s->comm.allgather(s->comm.ctx, mine, all.data(), sizeof(mine)) != 0)
+    if (s->gather(mine, all.data(), sizeof(mine)) != 0)
         {
         set_last_error("communicator allgather failed");
         return PGSD_ERROR_COMM;
@@ -428,7 +460,8 @@ static void destroy_impl(Impl* s)
 static Impl* new_impl()
     {
     Impl* s = new Impl;
-    s->comm = default_comm();
+    s->comm_box = default_comm_box();
+    s->comm = s->comm_box->c;
     s->rank = s->comm.rank;
     s->P = s->comm.size;
     memset(&s->header, 0, sizeof(s->header));
@@ -526,6 +559,7 @@ static int expand_file_index(Impl* s, size_t size_required, int* local_rc)
 
     // The new block goes to the TRUE end of the file as rank 0 sees it
     // (MPI_File_get_size, pgsd.c:1015) once every rank's data is in the file.
+    s->n_collectives++;
     int brc = comm_barrier(s->comm);
     if (brc != PGSD_SUCCESS)
         return brc;
@@ -587,19 +621,27 @@ static int expand_file_index(Impl* s, size_t size_required, int* local_rc)
     return PGSD_SUCCESS;
     }
 
-// pgsd_flush, pgsd.c:1955-2070
-static int do_flush(Impl* s, bool async = false)
+static int resolve_queue(Impl* s);
+static void remember_failure(Impl* s, int rc, int err);
+
+// pgsd_flush, pgsd.c:1955-2070.  sync_point: the call must leave every rank's bytes of the sealed
+// frames in the file and every rank with the same verdict (pgsd_flush, pgsd_close, reads; and
+// pgsd_end_frame unless the frame exchange is batched).
+static int do_flush(Impl* s, bool async = false, bool sync_point = true)
     {
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
 
+    // chunks still waiting for their placement are placed first (one exchange)
+    const int qrc = s->queue.empty() ? PGSD_SUCCESS : resolve_queue(s);
+
     // Replicated state tells every rank alike whether there is anything to do.
     bool work = s->frame_n_names > 0 || !s->buffer_index.empty() || !s->frame_index.empty()
-                || s->dirty_data || s->inflight;
+                || s->dirty_data || s->inflight || (sync_point && s->unsynced);
     for (uint64_t b : s->wb_sizes)
         work = work || b > 0;
     if (!work)
-        return PGSD_SUCCESS;
+        return qrc;
 
     // Asynchronous sealing commits the metadata now and lets the device chunks finish in
     // the background -- unless the on-disk index must move, which needs the file's true end
@@ -691,7 +733,19 @@ static int do_flush(Impl* s, bool async = false)
     s->dirty_data = false;
     if (sticky_errno)
         errno = sticky_errno;
-    return agree_status(s, local_rc);
+    if (s->batch && !sync_point && s->P > 1)
+        {
+        // batched frame exchange: no second collective per frame.  This rank's verdict is returned now
+        // and travels to the others with the next exchange; the barrier that guarantees every rank's
+        // rows are in the file is made up at the next synchronisation point.
+        if (local_rc != PGSD_SUCCESS)
+            remember_failure(s, local_rc, errno);
+        s->unsynced = true;
+        return local_rc != PGSD_SUCCESS ? local_rc : qrc;
+        }
+    s->unsynced = false;
+    const int arc = agree_status(s, local_rc);
+    return arc != PGSD_SUCCESS ? arc : qrc;
     }
 
 static int do_end_frame(Impl* s, bool async = false)
@@ -699,11 +753,14 @@ static int do_end_frame(Impl* s, bool async = false)
     // pgsd.c:1916-1953
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    // queued chunks belong to the frame that is being sealed: place them before the counter moves
+    const int qrc = s->queue.empty() ? PGSD_SUCCESS : resolve_queue(s);
     s->cur_frame++;
     s->pending = 0;
+    int rc = PGSD_SUCCESS;
     if (!s->frame_index.empty() || s->buffer_index.size() > s->idxbuf)
-        return do_flush(s, async);
-    return PGSD_SUCCESS;
+        rc = do_flush(s, async, !s->batch);
+    return qrc != PGSD_SUCCESS ? qrc : rc;
     }
 
 // name -> id; new names get the next id in first-seen order (pgsd.c:2111-2133, 1340-1404)
@@ -779,7 +836,7 @@ static int exchange_counts(Impl* s, uint64_t mine, int local_rc, std::vector<uin
         }
     uint64_t send[2] = {mine, (uint64_t)(uint32_t)local_rc | ((uint64_t)(uint32_t)(local_rc ? errno : 0) << 32)};
     std::vector<uint64_t> recv((size_t)s->P * 2);
-    if (s->comm.allgather(s->comm.ctx, send, recv.data(), sizeof(send)) != 0)
+    if (s->gather(send, recv.data(), sizeof(send)) != 0)
         {
         set_last_error("communicator allgather failed");
         return PGSD_ERROR_COMM;
@@ -797,6 +854,24 @@ static int exchange_counts(Impl* s, uint64_t mine, int local_rc, std::vector<uin
             }
         }
     return rc;
+    }
+
+// PGSD_PARTITION_AUTO: the partition the reference's callers obtain with an MPI_Allgather of their own
+// (benchmark-write.cc:39-45, fl.pyx:596-598) comes out of the size exchange instead.  sizes[r] / unit
+// = rows of rank r; the global count and this rank's first element follow.
+static void auto_partition(const Impl* s, const std::vector<uint64_t>& sizes, uint64_t unit, uint32_t M,
+                           uint64_t* N_global, uint64_t* offset_elems)
+    {
+    uint64_t total = 0, before = 0;
+    for (int r = 0; r < s->P; r++)
+        {
+        const uint64_t rows = unit ? sizes[(size_t)r] / unit : 0;
+        if (r < s->rank)
+            before += rows;
+        total += rows;
+        }
+    *N_global = total;
+    *offset_elems = before * M;
     }
 
 // Decide where a chunk's bytes go exactly as pgsd_write_chunk decides (pgsd.c:2143-2256) and record
@@ -894,6 +969,158 @@ static int ensure_device(Impl* s)
         return PGSD_ERROR_NO_DEVICE;
         }
     return PGSD_SUCCESS;
+    }
+// Hand the rows of a placed chunk to where the placement says.
+static int deliver_chunk(Impl* s, Queued& q, const Placement& pl, bool skip)
+    {
+    if (q.ticket >= 0)
+        {
+        std::string err;
+        int rc;
+        if (skip || pl.size == 0 || (!pl.buffered && !pl.write))
+            rc = device_pipeline_commit(s->dev, q.ticket, q.ticket_index, -1, nullptr, &err);
+        else if (pl.buffered)
+            {
+            const size_t at = s->write_buffer.size();
+            s->write_buffer.resize(at + pl.size, 0); // every rank has accounted for this length already
+            rc = device_pipeline_commit(s->dev, q.ticket, q.ticket_index, -1, s->write_buffer.data() + at, &err);
+            }
+        else
+            rc = device_pipeline_commit(s->dev, q.ticket, q.ticket_index, pl.file_offset, nullptr, &err);
+        if (rc != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            remember_failure(s, rc, 0);
+            }
+        return rc;
+        }
+    if (skip || pl.size == 0)
+        return PGSD_SUCCESS;
+    const char* data = q.borrowed ? (const char*)q.borrowed : q.host.data();
+    if (pl.buffered)
+        {
+        s->write_buffer.insert(s->write_buffer.end(), data, data + pl.size);
+        return PGSD_SUCCESS;
+        }
+    if (!pl.write)
+        return PGSD_SUCCESS;
+    // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
+    int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
+    if (e != 0)
+        {
+        errno = -e;
+        remember_failure(s, PGSD_ERROR_IO, -e);
+        return PGSD_ERROR_IO;
+        }
+    return PGSD_SUCCESS;
+    }
+
+// The frame exchange: ONE allgather carries, for every rank, its status word (a failure it has not
+// shared yet), the number of queued chunks and each chunk's byte count (or, top bit set, the code its
+// argument check failed with).  Every rank then replays the reference's placement decisions
+// (pgsd.c:2143-2256) for the queued chunks in call order -- max and sum of the sizes decide buffered or
+// direct and how far the file advances -- so the bytes land exactly where per-chunk exchanges would
+// have put them.  Chunks whose rows are partitioned automatically (PGSD_PARTITION_AUTO) get their
+// global row count and this rank's first row from the same vector: no separate row-count allgather.
+static int resolve_queue(Impl* s)
+    {
+    const size_t k = s->queue.size();
+    const uint64_t FAILED = 1ull << 63;
+    std::vector<uint64_t> send(k + 2), recv;
+    send[0] = (uint64_t)(uint32_t)s->sticky_rc | ((uint64_t)(uint32_t)s->sticky_errno << 32);
+    send[1] = k;
+    for (size_t i = 0; i < k; i++)
+        {
+        const Queued& q = s->queue[i];
+        send[2 + i] = q.local_rc != PGSD_SUCCESS ? (FAILED | (uint64_t)(uint32_t)(-q.local_rc))
+                                                 : q.N * q.M * sizeof_type(q.type);
+        }
+    int first_rc = PGSD_SUCCESS;
+    if (s->P > 1)
+        {
+        recv.assign((k + 2) * (size_t)s->P, 0);
+        if (s->gather(send.data(), recv.data(), send.size() * sizeof(uint64_t)) != 0)
+            {
+            set_last_error("communicator allgather failed");
+            return PGSD_ERROR_COMM; // the queue stays: nothing sane can be placed
+            }
+        s->sticky_rc = PGSD_SUCCESS; // shared now
+        s->sticky_errno = 0;
+        for (int r = 0; r < s->P; r++)
+            {
+            const uint64_t* v = recv.data() + (size_t)r * (k + 2);
+            if (v[1] != k)
+                {
+                set_last_error("the ranks queued different numbers of chunks for this frame");
+                return PGSD_ERROR_COMM;
+                }
+            const int src = (int)(int32_t)(uint32_t)v[0];
+            if (src != PGSD_SUCCESS && first_rc == PGSD_SUCCESS)
+                {
+                first_rc = src;
+                errno = (int)(uint32_t)(v[0] >> 32);
+                }
+            }
+        }
+    else
+        {
+        recv = send;
+        if (s->sticky_rc != PGSD_SUCCESS)
+            {
+            first_rc = s->sticky_rc;
+            errno = s->sticky_errno;
+            s->sticky_rc = PGSD_SUCCESS;
+            s->sticky_errno = 0;
+            }
+        }
+    std::vector<Queued> queue;
+    queue.swap(s->queue);
+    std::vector<uint64_t> sizes((size_t)s->P);
+    for (size_t i = 0; i < k; i++)
+        {
+        Queued& q = queue[i];
+        int bad = PGSD_SUCCESS;
+        for (int r = 0; r < s->P; r++)
+            {
+            const uint64_t e = recv[(size_t)r * (k + 2) + 2 + i];
+            if (e & FAILED)
+                {
+                if (bad == PGSD_SUCCESS)
+                    bad = -(int)(uint32_t)(e & 0xffffffffu);
+                sizes[(size_t)r] = 0;
+                }
+            else
+                sizes[(size_t)r] = e;
+            }
+        Placement pl;
+        memset(&pl, 0, sizeof(pl));
+        int rc = bad;
+        if (rc == PGSD_SUCCESS)
+            {
+            uint64_t N_global = q.N_global, offset = q.offset;
+            if (N_global == PGSD_PARTITION_AUTO)
+                {
+                // rows of rank r = its bytes / bytes per row; this rank starts behind the lower ranks
+                const uint64_t rowbytes = (uint64_t)q.M * sizeof_type(q.type);
+                N_global = 0;
+                offset = 0;
+                for (int r = 0; r < s->P; r++)
+                    {
+                    const uint64_t rows = rowbytes ? sizes[(size_t)r] / rowbytes : 0;
+                    if (r < s->rank)
+                        offset += rows * q.M;
+                    N_global += rows;
+                    }
+                }
+            rc = place_chunk(s, q.name.c_str(), q.type, q.N, q.M, N_global, q.M_global, offset, q.all, sizes, &pl);
+            }
+        const int drc = deliver_chunk(s, q, pl, rc != PGSD_SUCCESS);
+        if (rc == PGSD_SUCCESS)
+            rc = drc;
+        if (rc != PGSD_SUCCESS && first_rc == PGSD_SUCCESS)
+            first_rc = rc;
+        }
+    return first_rc;
     }
     } // namespace pgsd_amd
 
@@ -1121,8 +1348,37 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
         return PGSD_ERROR_INVALID_ARGUMENT;
     (void)global_size; // dead in the reference as well (pgsd.c:2147-2151)
     const int local = check_chunk_args(s, name, N, M, flags, data != NULL);
+    if (s->batch)
+        {
+        // frame-batched exchange: a replicated chunk below the buffer limit waits (with a copy of its
+        // rows) for the frame's exchange; a chunk that needs its file offset now -- per-particle rows,
+        // or more bytes than the buffer takes -- resolves the queue, itself included, at once
+        Queued q;
+        q.name = name ? name : "";
+        q.type = (uint32_t)type;
+        q.N = N, q.M = M, q.N_global = N_global, q.M_global = M_global, q.offset = offset, q.all = all;
+        q.local_rc = local;
+        const uint64_t size = local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0;
+        int rc = local;
+        if (local == PGSD_SUCCESS && (all || size >= s->maxbuf))
+            {
+            q.borrowed = data;
+            s->queue.push_back(std::move(q));
+            rc = resolve_queue(s);
+            }
+        else
+            {
+            if (size > 0)
+                q.host.assign((const char*)data, (const char*)data + size);
+            s->queue.push_back(std::move(q));
+            }
+        publish(handle, s);
+        return rc;
+        }
     std::vector<uint64_t> sizes;
     int rc = exchange_counts(s, local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0, local, sizes);
+    if (rc == PGSD_SUCCESS && N_global == PGSD_PARTITION_AUTO)
+        auto_partition(s, sizes, (uint64_t)M * sizeof_type((uint32_t)type), M, &N_global, &offset);
     Placement pl;
     if (rc == PGSD_SUCCESS)
         rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, all, sizes, &pl);
@@ -1361,6 +1617,12 @@ extern "C" int pgsd_set_maximum_write_buffer_size(struct pgsd_handle* handle, ui
     Impl* s = impl_of(handle);
     if (!s || size == 0)
         return PGSD_ERROR_INVALID_ARGUMENT;
+    if (!s->queue.empty()) // queued chunks are placed under the limit they were written under
+        {
+        int rc = resolve_queue(s);
+        if (rc != PGSD_SUCCESS)
+            return rc;
+        }
     s->maxbuf = size;
     publish(handle, s);
     return PGSD_SUCCESS;
@@ -1397,6 +1659,63 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
+extern "C" int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = PGSD_SUCCESS;
+    if (!batched && s->batch && s->flags != PGSD_OPEN_READONLY)
+        rc = do_flush(s); // leave nothing queued and nothing unsynchronised behind
+    s->batch = batched != 0;
+    publish(handle, s);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_frame_exchange(struct pgsd_handle* handle)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    const int rc = s->queue.empty() ? PGSD_SUCCESS : resolve_queue(s);
+    publish(handle, s);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" uint64_t pgsd_get_collective_count(struct pgsd_handle* handle)
+    try
+    {
+    Impl* s = impl_of(handle);
+    return s ? s->n_collectives : 0;
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
+
+extern "C" int pgsd_get_frame_exchange(struct pgsd_handle* handle)
+    try
+    {
+    Impl* s = impl_of(handle);
+    return s && s->batch ? 1 : 0;
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }
+
 // ---------------------------------------------------------------------------- device path
 
 extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg)
@@ -1407,6 +1726,12 @@ extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pg
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (s->dev)
         {
+        if (!s->queue.empty()) // packed chunks of the old pipeline still wait for their placement
+            {
+            int qrc = resolve_queue(s);
+            if (qrc != PGSD_SUCCESS)
+                return qrc;
+            }
         std::string err;
         int rc = device_pipeline_drain(s->dev, &err);
         if (rc != PGSD_SUCCESS)
@@ -1460,8 +1785,40 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
         local = check_field(src, (uint32_t)type, M);
     if (local == PGSD_SUCCESS)
         local = ensure_device(s);
+    if (s->batch)
+        {
+        // pack now (the kernel needs no file offset), place at the frame's exchange
+        Queued q;
+        q.name = name ? name : "";
+        q.type = (uint32_t)type;
+        q.N = N, q.M = M, q.N_global = N_global, q.M_global = M_global, q.offset = offset, q.all = all;
+        q.local_rc = local;
+        if (local == PGSD_SUCCESS)
+            {
+            std::vector<DeviceChunk> chunks(1);
+            memset(&chunks[0], 0, sizeof(DeviceChunk));
+            chunks[0].job.dst_type = (uint32_t)type;
+            chunks[0].job.M = M;
+            if (N > 0)
+                chunks[0].job.src = *src;
+            chunks[0].N = N;
+            std::string err;
+            q.local_rc = device_pipeline_stage(s->dev, chunks, N, &q.ticket, &err);
+            if (q.local_rc != PGSD_SUCCESS)
+                {
+                set_last_error(err);
+                q.ticket = -1;
+                }
+            }
+        const int rc = q.local_rc;
+        s->queue.push_back(std::move(q));
+        publish(handle, s);
+        return rc;
+        }
     std::vector<uint64_t> sizes;
     int rc = exchange_counts(s, local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0, local, sizes);
+    if (rc == PGSD_SUCCESS && N_global == PGSD_PARTITION_AUTO)
+        auto_partition(s, sizes, (uint64_t)M * sizeof_type((uint32_t)type), M, &N_global, &offset);
     Placement pl;
     if (rc == PGSD_SUCCESS)
         rc = place_chunk(s, name, (uint32_t)type, N, M, N_global, M_global, offset, all, sizes, &pl);
@@ -1520,10 +1877,55 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
         }
     if (local == PGSD_SUCCESS)
         local = ensure_device(s);
+    if (s->batch)
+        {
+        // one fused pack launch now, placement of every chunk at the frame's exchange
+        int ticket = -1;
+        if (local == PGSD_SUCCESS)
+            {
+            std::vector<DeviceChunk> staged(n_chunks);
+            for (uint32_t i = 0; i < n_chunks; i++)
+                {
+                memset(&staged[i], 0, sizeof(DeviceChunk));
+                staged[i].job.dst_type = reqs[i].type;
+                staged[i].job.M = reqs[i].M;
+                staged[i].job.src = reqs[i].src;
+                staged[i].N = N;
+                }
+            std::string err;
+            local = device_pipeline_stage(s->dev, staged, N, &ticket, &err);
+            if (local != PGSD_SUCCESS)
+                {
+                set_last_error(err);
+                ticket = -1;
+                }
+            }
+        for (uint32_t i = 0; i < n_chunks; i++)
+            {
+            Queued q;
+            q.name = reqs[i].name ? reqs[i].name : "";
+            q.type = reqs[i].type;
+            q.N = N, q.M = reqs[i].M, q.N_global = N_global, q.M_global = reqs[i].M;
+            q.offset = offset_rows * reqs[i].M;
+            q.all = true;
+            q.local_rc = local;
+            q.ticket = ticket;
+            q.ticket_index = i;
+            s->queue.push_back(std::move(q));
+            }
+        publish(handle, s);
+        return local;
+        }
     // ONE exchange for all chunks of the call: they share the row count, so every rank's byte
     // count of chunk i is rows[r] * M_i * sizeof(type_i)
     std::vector<uint64_t> rows;
     int rc = exchange_counts(s, N, local, rows);
+    if (rc == PGSD_SUCCESS && N_global == PGSD_PARTITION_AUTO)
+        {
+        uint64_t off_elems = 0;
+        auto_partition(s, rows, 1, 1, &N_global, &off_elems);
+        offset_rows = off_elems;
+        }
     std::vector<DeviceChunk> chunks;
     std::vector<uint64_t> sizes((size_t)s->P);
     for (uint32_t i = 0; i < n_chunks && rc == PGSD_SUCCESS; i++)

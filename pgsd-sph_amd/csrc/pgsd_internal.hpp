@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <sched.h>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,22 @@ const char* last_error();
 // crosses the boundary.  Maps the exception in flight to a pgsd_error and records its text.
 int abi_guard() noexcept;
 pgsd_comm default_comm();
+// The installed communicator is shared by reference: a handle keeps the one it was opened with alive, so
+// pgsd_comm_finalize / pgsd_comm_init_* while files are open cannot pull the context (shm mapping, RCCL
+// communicator, callbacks) from under them; its destroy hook runs when the last user lets go.
+struct CommBox
+    {
+    pgsd_comm c;
+    explicit CommBox(const pgsd_comm& comm) : c(comm) { }
+    CommBox(const CommBox&) = delete;
+    CommBox& operator=(const CommBox&) = delete;
+    ~CommBox()
+        {
+        if (c.destroy)
+            c.destroy(c.ctx);
+        }
+    };
+std::shared_ptr<CommBox> default_comm_box();
 
 inline int comm_barrier(const pgsd_comm& c)
     {
@@ -60,6 +77,11 @@ DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, bo
 void device_pipeline_destroy(DevicePipeline*);
 // one fused pack launch for `chunks` (all share N), then async copy + write of each
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
+// the same in two steps: pack now (one fused launch, returns a ticket), say later where chunk `index` of the
+// ticket goes: a file offset, a host buffer (synchronous copy), or nowhere (file_offset < 0, host_dst null)
+int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, int* ticket, std::string* err);
+int device_pipeline_commit(DevicePipeline*, int ticket, size_t index, long long file_offset, void* host_dst,
+                           std::string* err);
 int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
 void device_pipeline_set_source_stream(DevicePipeline*, void* stream);
 // read side: rows at `file_offset` -> staging -> unpack into job.dst (job.src is filled in)

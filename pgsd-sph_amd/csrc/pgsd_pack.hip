@@ -1866,6 +1866,39 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
+extern "C" int pgsd_pack_fields_timed(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream,
+                                      float* kernel_ms)
+    try
+    {
+    if ((n_jobs > 0 && !jobs) || !kernel_ms)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    *kernel_ms = 0.f;
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_pack_fields_timed: no HIP device visible (the HIP path has no CPU fallback)");
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return PGSD_ERROR_DEVICE;
+    std::string err;
+    int rc = launch_pack(n_jobs, jobs, N, (hipStream_t)stream, &err, e0, e1);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    else if (n_jobs > 0 && N > 0)
+        {
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(kernel_ms, e0, e1) != hipSuccess)
+            rc = PGSD_ERROR_DEVICE;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
 extern "C" size_t pgsd_select_workspace_bytes(uint64_t N)
     try
     {

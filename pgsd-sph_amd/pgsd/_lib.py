@@ -45,6 +45,7 @@ ERROR_FILE_MUST_BE_READABLE = -9
 ERROR_DEVICE = -20
 ERROR_COMM = -21
 ERROR_NO_DEVICE = -22
+PARTITION_AUTO = 2 ** 64 - 1      # PGSD_PARTITION_AUTO
 
 
 class Header(ctypes.Structure):
@@ -177,6 +178,11 @@ _sig("pgsd_device_set_source_stream", c_i32, HP, c_vp)
 _sig("pgsd_device_configure", c_i32, HP, ctypes.POINTER(DeviceConfig))
 _sig("pgsd_device_get_stats", c_i32, HP, ctypes.POINTER(DeviceStats), c_i32)
 _sig("pgsd_pack_fields", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp)
+_sig("pgsd_pack_fields_timed", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp, ctypes.POINTER(ctypes.c_float))
+_sig("pgsd_set_frame_exchange", c_i32, HP, c_i32)
+_sig("pgsd_get_frame_exchange", c_i32, HP)
+_sig("pgsd_frame_exchange", c_i32, HP)
+_sig("pgsd_get_collective_count", c_u64, HP)
 _sig("pgsd_unpack_fields", c_i32, c_u32, ctypes.POINTER(UnpackJob), c_u64, c_vp)
 _sig("pgsd_read_chunk_device", c_i32, HP, ctypes.POINTER(IndexEntry), c_u64, c_u64, ctypes.POINTER(FieldDst))
 _sig("pgsd_device_wait_read", c_i32, HP)

@@ -17,11 +17,19 @@ from . import _lib
 from ._lib import lib
 
 _keep = {}
+_retired = []   # callbacks of earlier communicators: open files may still hold them (the C side keeps a
+                # communicator alive until the last handle opened with it is closed)
+
+
+def _retire():
+    if "cb" in _keep:
+        _retired.append(_keep.pop("cb"))
+    _keep.clear()
 
 
 def init_self():
     lib.pgsd_comm_init_self()
-    _keep.clear()
+    _retire()
 
 
 def init_shm(name, rank, size):
@@ -112,13 +120,14 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
     rc = lib.pgsd_comm_set_default(ctypes.byref(comm))
     if rc != 0:
         raise RuntimeError("pgsd_comm_set_default failed")
+    _retire()
     _keep["cb"] = (cb_ag, cb_bar, comm)
     return "torch-" + backend
 
 
 def finalize():
     lib.pgsd_comm_finalize()
-    _keep.clear()
+    _retire()
 
 
 def partition_rows(n_local):

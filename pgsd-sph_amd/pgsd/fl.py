@@ -293,6 +293,7 @@ class PGSDFile(object):
             retval = lib.pgsd_close(self._h())
             self.__is_open = False
             self.__keepalive = []
+            self.__async_keep = []
             _raise_on_error(retval, self.__name)
 
     def end_frame(self, write_all=True, wait=True):
@@ -308,11 +309,19 @@ class PGSDFile(object):
         logger.debug('end frame: ' + self.__name)
         if wait:
             retval = lib.pgsd_end_frame(self._h())
+            # a synchronous seal drains the pipeline: nothing sealed earlier still reads its sources
             self.__keepalive = []
+            self.__async_keep = []
         else:
             retval = lib.pgsd_end_frame_async(self._h())
             self.__async_keep.append(self.__keepalive)
             self.__keepalive = []
+            # The pack kernels read the source arrays, the copies and writes read the staging arena: once
+            # a frame's kernels are done its sources may go.  Only the newest frames can still be packing;
+            # keep two, sync-free, so a long run of append(wait=False) does not pin every frame's tensors.
+            if len(self.__async_keep) > 2:
+                _raise_on_error(lib.pgsd_device_wait_packed(self._h()), self.__name)
+                self.__async_keep = self.__async_keep[-1:]
         _raise_on_error(retval, self.__name)
 
     def frame_sync(self):
@@ -327,7 +336,36 @@ class PGSDFile(object):
         self._check_open()
         logger.debug('flush: ' + self.__name)
         retval = lib.pgsd_flush(self._h())
+        self.__async_keep = []
         _raise_on_error(retval, self.__name)
+
+    @property
+    def frame_exchange(self):
+        """bool: batch the exchange between the ranks per frame (``pgsd_set_frame_exchange``).
+
+        Off (default): every chunk write exchanges the ranks' sizes at once, like the reference's per-chunk
+        collectives.  On: replicated small chunks and all device chunks are queued and ONE allgather at
+        :meth:`end_frame` carries their sizes and the ranks' status -- a frame of small chunks, fused device
+        chunks (``offset='auto'``) and ``end_frame`` costs one collective.  The file is byte-identical
+        either way."""
+        self._check_open()
+        return bool(lib.pgsd_get_frame_exchange(self._h()))
+
+    @frame_exchange.setter
+    def frame_exchange(self, on):
+        self._check_open()
+        _raise_on_error(lib.pgsd_set_frame_exchange(self._h(), 1 if on else 0), self.__name)
+
+    def exchange_now(self):
+        """Perform the pending frame exchange now (collective; nothing is flushed)."""
+        self._check_open()
+        _raise_on_error(lib.pgsd_frame_exchange(self._h()), self.__name)
+
+    @property
+    def collective_count(self):
+        """int: allgathers / barriers this handle has issued on its communicator."""
+        self._check_open()
+        return int(lib.pgsd_get_collective_count(self._h()))
 
     # ------------------------------------------------------------------ writing
     def write_chunk(self, name, data, offset=None, rank=0, write_all=True):
@@ -339,7 +377,8 @@ class PGSDFile(object):
                 reference), or a torch GPU tensor / :class:`DeviceField` (device path).
             offset: ``None`` or the integer array of every rank's row count; with ``rank`` it
                 gives ``N_global = offset.sum()`` and this rank's first row
-                ``offset[:rank].sum()`` (fl.pyx:594-598).
+                ``offset[:rank].sum()`` (fl.pyx:594-598).  ``'auto'``: rows partitioned in rank order,
+                counts taken from the library's own size exchange.
             rank (int): this rank.
             write_all (bool): ``True``: every rank writes its rows of a per-particle chunk;
                 ``False``: replicated small chunk.
@@ -358,19 +397,27 @@ class PGSDFile(object):
             data_array = data_array.reshape([data_array.shape[0], 1])
         N = data_array.shape[0]
         M = data_array.shape[1]
-        N_global = N
-        stride = 0
-        if offset is not None:
-            offset = numpy.asarray(offset)
-            N_global = int(offset.sum())
-            stride = M * int(offset[0:rank].sum())
+        N_global, stride = self._partition_args(offset, rank, N, M)
         pgsd_type = _pgsd_type(data_array.dtype, name)
         ptr = data_array.ctypes.data if data_array.size else None
         logger.debug('write chunk: ' + self.__name + ' - ' + name)
         ctypes.set_errno(0)
         retval = lib.pgsd_write_chunk(self._h(), name.encode('utf-8'), pgsd_type, N, M, N_global, M,
-                                      stride, N_global * M, bool(write_all), 0, ptr)
+                                      stride, (N_global * M) % 2 ** 64, bool(write_all), 0, ptr)
         _raise_on_error(retval, self.__name)
+
+    @staticmethod
+    def _partition_args(offset, rank, N, M):
+        """``offset`` of :meth:`write_chunk` -> (N_global, element offset of this rank), fl.pyx:594-598.
+        ``'auto'``: the library derives both from its own size exchange (PGSD_PARTITION_AUTO)."""
+        if isinstance(offset, str):
+            if offset != 'auto':
+                raise ValueError("offset must be None, 'auto' or the array of every rank's row count")
+            return _lib.PARTITION_AUTO, 0
+        if offset is None:
+            return N, 0
+        offset = numpy.asarray(offset)
+        return int(offset.sum()), M * int(offset[0:rank].sum())
 
     def _sync_source_stream(self):
         """Tell the pipeline which stream produced the arrays: PyTorch's current stream."""
@@ -390,17 +437,12 @@ class PGSDFile(object):
             self._sync_source_stream()
         f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
         N, M = f.N, f.M
-        N_global = N
-        stride = 0
-        if offset is not None:
-            offset = numpy.asarray(offset)
-            N_global = int(offset.sum())
-            stride = M * int(offset[0:rank].sum())
+        N_global, stride = self._partition_args(offset, rank, N, M)
         desc = f._desc()
         self.__keepalive.append(f)
         ctypes.set_errno(0)
         retval = lib.pgsd_write_chunk_device(self._h(), name.encode('utf-8'), _pgsd_type(f.out_dtype, name),
-                                             N, M, N_global, M, stride, N_global * M, bool(write_all), 0,
+                                             N, M, N_global, M, stride, (N_global * M) % 2 ** 64, bool(write_all), 0,
                                              ctypes.byref(desc))
         _raise_on_error(retval, self.__name)
 
@@ -410,7 +452,9 @@ class PGSDFile(object):
         Args:
             fields: list of ``(name, data)`` with ``data`` a torch GPU tensor or a
                 :class:`DeviceField`; all must have the same number of rows.
-            offset, rank: as in :meth:`write_chunk` (``write_all`` is implied).
+            offset, rank: as in :meth:`write_chunk` (``write_all`` is implied); ``offset='auto'`` lets the
+                library derive the partition from its own size exchange, so no row-count allgather of the
+                caller is needed.
         """
         self._check_open()
         if not self.__explicit_stream:
@@ -424,11 +468,7 @@ class PGSDFile(object):
         N = specs[0][1].N
         if any(f.N != N for _, f in specs):
             raise ValueError("all fields of a fused write must have the same number of rows")
-        N_global, row0 = N, 0
-        if offset is not None:
-            offset = numpy.asarray(offset)
-            N_global = int(offset.sum())
-            row0 = int(offset[0:rank].sum())
+        N_global, row0 = self._partition_args(offset, rank, N, 1)
         reqs = (_lib.ChunkReq * len(specs))()
         names = []
         for i, (name, f) in enumerate(specs):

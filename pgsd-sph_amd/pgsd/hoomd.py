@@ -319,21 +319,18 @@ class HOOMDTrajectory(object):
         frame.validate()
         rank, size = self._comm()
 
-        # per-rank particle counts -> file offsets (the allgather of benchmark-write.cc:41)
-        if frame.part_dist is not None:
-            part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
-            if part_dist.shape[0] != size:
-                raise ValueError("part_dist must have one entry per rank")
-        else:
-            from . import dist as _dist
-            part_dist, _, _ = _dist.partition_rows(int(frame.particles.N))
-        n_global = int(part_dist.sum())
-
         # the initial frame is the reference for elision
         if self._initial_frame is None and len(self) > 0:
             self._read_frame(0)
 
-        # 1. decide which chunks to write (local), then agree over the ranks
+        # From here on the frame costs two collectives however many chunks it has: the allgather below
+        # (row counts + write/skip votes) and the one frame exchange of end_frame, which places every
+        # queued chunk (pgsd_set_frame_exchange; the file is byte-identical to the unbatched one).
+        if getattr(self.file, 'frame_exchange', None) is False:
+            self.file.frame_exchange = True
+
+        # 1. decide locally which chunks to write, then ONE allgather carries every rank's particle count
+        #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes
         plan = []
         for path in ('configuration', 'particles', 'constraints'):
             container = getattr(frame, path)
@@ -341,18 +338,35 @@ class HOOMDTrajectory(object):
             if path == 'particles':
                 names += list(container._extra_default_value)
             for name in names:
-                plan.append((path, name, self._should_write(path, name, frame, n_global)))
+                if (path, name) == ('particles', 'N'):
+                    plan.append((path, name, False))      # decided below from the global count
+                else:
+                    plan.append((path, name, self._should_write(path, name, frame, None)))
+        if frame.part_dist is not None:
+            part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
+            if part_dist.shape[0] != size:
+                raise ValueError("part_dist must have one entry per rank")
+        else:
+            part_dist = numpy.array([int(frame.particles.N)], dtype=numpy.uint64)
         if size > 1:
             from ._lib import lib
             import ctypes
-            mine = numpy.array([1 if w else 0 for _, _, w in plan], dtype=numpy.uint8)
+            mine = numpy.zeros(8 + len(plan), dtype=numpy.uint8)
+            mine[:8] = numpy.array([int(frame.particles.N)], dtype=numpy.uint64).view(numpy.uint8)
+            mine[8:] = [1 if w else 0 for _, _, w in plan]
             allb = numpy.zeros(size * len(mine), dtype=numpy.uint8)
             rc = lib.pgsd_comm_allgather(mine.ctypes.data_as(ctypes.c_void_p), allb.ctypes.data_as(ctypes.c_void_p),
                                          len(mine))
             if rc != 0:
                 raise RuntimeError("communicator allgather failed")
-            agreed = allb.reshape(size, len(mine)).max(axis=0)
+            allb = allb.reshape(size, len(mine))
+            if frame.part_dist is None:
+                part_dist = numpy.ascontiguousarray(allb[:, :8]).view(numpy.uint64).reshape(size)
+            agreed = allb[:, 8:].max(axis=0)
             plan = [(p, n, bool(a)) for (p, n, _), a in zip(plan, agreed)]
+        n_global = int(part_dist.sum())
+        plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') else w)
+                for p, n, w in plan]
 
         # 2. write, in the reference's chunk order; device fields go out in one fused launch
         device_fields = []

@@ -39,6 +39,9 @@
  *   chunkgs <name> <type> <M> <all> <dist> <global_size>
  *         (as chunk, but the caller's global_size argument is the given value, right or wrong:
  *          the reference ignores it, pgsd.c:2147-2151, 2240-2246)
+ *   batch <0|1>                    (product only: pgsd_set_frame_exchange; ignored by the reference build.
+ *                                   `dump` then performs the pending exchange first, so that the trace
+ *                                   shows the same file_size the unbatched run shows)
  *   end_frame | flush | close | dump
  *   maxbuf <bytes> | idxbuf <entries>
  *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
@@ -326,8 +329,18 @@ int main(int argc, char** argv)
             rc = pgsd_set_maximum_write_buffer_size(&handle, strtoull(tok[1], NULL, 10));
         else if (strcmp(cmd, "idxbuf") == 0 && nt == 2)
             rc = pgsd_set_index_entries_to_buffer(&handle, strtoull(tok[1], NULL, 10));
+        else if (strcmp(cmd, "batch") == 0 && nt == 2)
+            {
+#ifndef PGSD_DRIVER_REF
+            rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]));
+#endif
+            }
         else if (strcmp(cmd, "dump") == 0)
             {
+#ifndef PGSD_DRIVER_REF
+            if (pgsd_get_frame_exchange(&handle))
+                rc = pgsd_frame_exchange(&handle);
+#endif
             uint64_t nf = pgsd_get_nframes(&handle);
             uint64_t nn = pgsd_get_nnames(&handle);
             if (g_rank == 0)

@@ -1,7 +1,7 @@
 """Child process of tests/test_io_errors.py: writes frames until the file-size limit of THIS rank
 makes pwrite fail, and reports what every call raised.
 
-usage: io_error_worker.py <path> <rank> <nranks> <shm name> <limited: 0|1> <device: 0|1>"""
+usage: io_error_worker.py <path> <rank> <nranks> <shm name> <limited: 0|1> <device: 0|1> [batched: 0|1]"""
 import json
 import os
 import resource
@@ -15,6 +15,7 @@ import numpy as np
 
 path, rank, nranks, shm, limited, device = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], \
     int(sys.argv[5]), int(sys.argv[6])
+batched = len(sys.argv) > 7 and sys.argv[7] == "1"
 signal.signal(signal.SIGXFSZ, signal.SIG_IGN)      # a write past the limit returns EFBIG instead of killing us
 
 import pgsd.dist as pdist
@@ -26,6 +27,8 @@ N = 300_000
 counts = np.array([N] * nranks, dtype=np.uint64)
 report = {"rank": rank, "events": []}
 f = fl.open(path, 'w', application='io-error test', schema='s', schema_version=[1, 0])
+if batched:
+    f.frame_exchange = True     # one exchange per frame: a failure reaches the other ranks with the next one
 if device:
     import torch
     data = torch.arange(N * 3, dtype=torch.float32, device="cuda").reshape(N, 3) + rank
@@ -57,6 +60,8 @@ if limited:
     hard = resource.getrlimit(resource.RLIMIT_FSIZE)[1]
     resource.setrlimit(resource.RLIMIT_FSIZE, (1 << 20, hard))          # the next frame does not fit
 frame("after")
+if batched:
+    frame("later")
 record("close", f.close)
 if nranks > 1:
     pdist.finalize()

@@ -48,3 +48,17 @@ def run_driver(script, out_path, P, timeout=120, allow_fail=False):
         if p.returncode != 0 and not (allow_fail and p.returncode == 1):
             raise RuntimeError("scenario driver rank %d exited with %s" % (r, p.returncode))
     return [ln for ln in out.decode().splitlines() if ln.strip()]
+
+
+def batched_script(path, out_path):
+    """The same scenario with the frame exchange batched (pgsd_set_frame_exchange) on every handle."""
+    lines = []
+    with open(path) as f:
+        for line in f:
+            lines.append(line)
+            tok = line.split("#", 1)[0].split()
+            if tok and (tok[0] == "create" or (tok[0] == "open" and tok[1] != "ro")):
+                lines.append("batch 1\n")
+    with open(out_path, "w") as f:
+        f.writelines(lines)
+    return out_path

@@ -202,6 +202,8 @@ def run_oracle(script, out_path, P):
             rc = rc_ref.value
         elif cmd == "seed":
             seed = int(tok[1])
+        elif cmd == "batch":
+            pass    # product only (pgsd_set_frame_exchange): the layout must not depend on it
         elif cmd == "chunk":
             name, t, M, all_, dist = tok[1], TYPE_IDS[tok[2]], int(tok[3]), int(tok[4]), tok[5]
             counts = dist_counts(dist, P)

@@ -1,0 +1,167 @@
+"""The batched frame exchange (pgsd_set_frame_exchange): how many collectives a frame costs.
+
+A fake two-rank communicator lives in this process: rank 0 is real, the allgather callback answers for a
+peer that sends exactly what rank 0 sends (same calls, same sizes) and counts the calls.  The layout side
+of the batching -- files byte-identical to the reference's -- is covered by the golden and fuzz suites
+(tests/test_product_golden.py, tests/test_fuzz_parity.py: every scenario replayed with `batch 1`)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from pgsd import _lib
+import pgsd.fl as fl
+
+
+class MirrorComm:
+    """rank 0 of 2; the peer mirrors rank 0's contribution"""
+
+    def __init__(self):
+        self.calls = []
+
+        def allgather(ctx, send, recv, nbytes):
+            self.calls.append(nbytes)
+            ctypes.memmove(recv, send, nbytes)
+            ctypes.memmove(recv + nbytes, send, nbytes)
+            return 0
+
+        self._ag = _lib.ALLGATHER_FN(allgather)
+        comm = _lib.Comm()
+        comm.ctx = None
+        comm.rank, comm.size = 0, 2
+        comm.allgather = self._ag
+        assert _lib.lib.pgsd_comm_set_default(ctypes.byref(comm)) == 0
+        self._comm = comm
+
+    def close(self):
+        _lib.lib.pgsd_comm_finalize()
+
+
+@pytest.fixture
+def mirror():
+    m = MirrorComm()
+    yield m
+    m.close()
+
+
+def small_frame(f, i):
+    f.write_chunk("configuration/step", np.array([i], dtype=np.uint64), write_all=False)
+    f.write_chunk("configuration/box", np.arange(6, dtype=np.float32), write_all=False)
+    f.write_chunk("log/e", np.array([0.5 * i]), write_all=False)
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_collectives_per_frame_host_chunks(batched, mirror, tmp_gsd):
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    f.frame_exchange = batched
+    base = f.collective_count
+    per_frame = []
+    for i in range(4):
+        small_frame(f, i)
+        f.write_chunk("particles/position", np.full((5, 3), i, np.float32), offset=np.array([5, 5]), rank=0)
+        f.end_frame()
+        per_frame.append(f.collective_count - base - sum(per_frame))
+    # unbatched: one exchange per chunk + the status exchange of the flush; batched: the per-particle host
+    # chunk needs its offset at once and carries the three queued chunks with it -- one collective per frame
+    assert per_frame == ([1, 1, 1, 1] if batched else [5, 5, 5, 5])
+    assert f.collective_count == len(mirror.calls)       # the two exchanges of create/open included
+    f.close()           # the barrier the batched frames skipped is made up here (plus the final verdict)
+    assert f is not None
+
+
+def test_batched_frames_of_small_chunks_exchange_once_and_match_the_unbatched_file(mirror, tmp_path):
+    paths = []
+    for batched in (False, True):
+        p = str(tmp_path / ("b%d.gsd" % batched))
+        f = fl.open(p, "w", application="app", schema="hoomd", schema_version=[1, 4])
+        f.frame_exchange = batched
+        n0 = len(mirror.calls)
+        for i in range(5):
+            small_frame(f, i)
+            f.end_frame()
+        if batched:
+            assert len(mirror.calls) - n0 == 5          # one exchange per frame (3 sizes + status + count)
+            assert mirror.calls[-1] == 8 * (2 + 3)
+        else:
+            assert len(mirror.calls) - n0 == 15         # one per chunk; small chunks alone never flush
+        f.close()
+        paths.append(p)
+    with open(paths[0], "rb") as a, open(paths[1], "rb") as b:
+        assert a.read() == b.read()
+
+
+def test_auto_partition_equals_the_callers_allgather(mirror, tmp_path):
+    """offset='auto' (PGSD_PARTITION_AUTO): global row count and first row out of the chunk's own exchange."""
+    data = np.arange(21, dtype=np.float32).reshape(7, 3)
+    files = []
+    for auto in (False, True):
+        p = str(tmp_path / ("a%d.gsd" % auto))
+        f = fl.open(p, "w", application="app", schema="hoomd", schema_version=[1, 4])
+        f.write_chunk("particles/position", data, offset="auto" if auto else np.array([7, 7]), rank=0)
+        f.end_frame()
+        assert f.read_chunk(0, "particles/position").shape == (14, 3)
+        f.close()
+        files.append(p)
+    with open(files[0], "rb") as a, open(files[1], "rb") as b:
+        assert a.read() == b.read()
+
+
+def test_mirror_lags_until_the_exchange(tmp_gsd):
+    """Batched: file_size of the handle mirror moves when the queue is resolved, not per call."""
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    f.frame_exchange = True
+    small_frame(f, 0)
+    assert f.nframes == 0
+    f.exchange_now()
+    f.end_frame()
+    assert f.nframes == 1 and f.chunk_exists(0, "log/e")
+    f.frame_exchange = False
+    assert not f.frame_exchange
+    f.close()
+
+
+@pytest.mark.gpu
+def test_one_collective_per_device_frame(mirror, tmp_gsd):
+    """The bench / HOOMD-SPH frame: a replicated step chunk, three per-particle chunks packed by one fused
+    launch with the partition taken from the exchange, end_frame -- ONE allgather (it goes out after the
+    pack launch, so on the RCCL back end the ncclAllGather overlaps the kernel)."""
+    torch = pytest.importorskip("torch")
+    N = 5000
+    pos = torch.randn((N, 4), device="cuda")
+    vel = torch.randn((N, 4), device="cuda")
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    f.frame_exchange = True
+    fields = [("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
+              ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
+              ("particles/typeid", fl.DeviceField.from_tensor(pos, columns=(3, 4), out_dtype=np.uint32, bitcast=True))]
+    for i in range(3):
+        n0 = len(mirror.calls)
+        f.write_chunk("configuration/step", np.array([i], dtype=np.uint64), write_all=False)
+        f.write_chunks(fields, offset="auto")
+        f.end_frame()
+        assert len(mirror.calls) - n0 == 1
+        assert mirror.calls[-1] == 8 * (2 + 4)          # status, count, four chunk sizes
+    f.close()
+    g = fl.open(tmp_gsd, "r")
+    got = g.read_chunk(2, "particles/position")
+    assert got.shape == (2 * N, 3)                      # the mirrored peer "owns" the second half
+    np.testing.assert_array_equal(got[:N], pos[:, :3].cpu().numpy())
+    g.close()
+
+
+def test_a_handle_keeps_its_communicator_alive_across_finalize(mirror, tmp_gsd):
+    """pgsd_comm_finalize / re-initialisation while a file is open: the handle goes on using (and keeps
+    alive) the communicator it was opened with; the context is destroyed with the last handle, not under it."""
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    small_frame(f, 0)
+    f.end_frame()
+    assert _lib.lib.pgsd_comm_finalize() == 0 and _lib.lib.pgsd_comm_size() == 1
+    n0 = len(mirror.calls)
+    small_frame(f, 1)
+    f.write_chunk("particles/position", np.zeros((4, 3), np.float32), offset=np.array([4, 4]), rank=0)
+    f.end_frame()
+    f.close()
+    assert len(mirror.calls) > n0                      # still the two-rank communicator of the open
+    g = fl.open(tmp_gsd, "r")                          # a new handle sees the new (single-rank) default
+    assert g.nframes == 2 and g.read_chunk(1, "particles/position").shape == (8, 3)
+    g.close()

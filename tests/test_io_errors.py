@@ -15,10 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "io_error_worker.py")
 
 
-def run_ranks(path, nranks, limited_rank, device):
+def run_ranks(path, nranks, limited_rank, device, batched=False):
     shm = "pgsdioerr_%s" % uuid.uuid4().hex[:10]
     procs = [subprocess.Popen([sys.executable, WORKER, path, str(r), str(nranks), shm,
-                               "1" if r == limited_rank else "0", "1" if device else "0"],
+                               "1" if r == limited_rank else "0", "1" if device else "0", "1" if batched else "0"],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(nranks)]
     reports = []
     try:
@@ -68,3 +68,29 @@ def test_device_pipeline_write_failure(tmp_gsd):
 @pytest.mark.gpu
 def test_device_pipeline_write_failure_two_ranks_sharing_the_gpu(tmp_gsd):
     check(run_ranks(tmp_gsd, 2, 1, device=True), 1, device=True)
+
+
+def check_batched(reports, limited_rank, device=False):
+    """Batched frame exchange (pgsd_set_frame_exchange): ONE collective per frame, so the failing rank knows
+    at once, the others with the next exchange -- the next frame's, or the one pgsd_close makes.  Nobody
+    dead-locks, nobody misses it."""
+    for rep in reports:
+        ev = {e[0]: e[1:] for e in rep["events"]}
+        assert ev["before:write"] == ["ok"] and ev["before:end_frame"] == ["ok"], rep
+        errors = [k for k, v in ev.items() if v[0] == "OSError"]
+        assert errors and all(ev[k][1] == errno.EFBIG for k in errors), rep
+        if rep["rank"] == limited_rank:
+            first = "after:end_frame" if device else "after:write"
+            assert ev[first][0] == "OSError", rep
+        assert not [k for k in errors if k.startswith("before")], rep
+        assert "close" in ev, rep
+
+
+@pytest.mark.parametrize("limited_rank", [0, 1])
+def test_write_failure_with_batched_frame_exchange_reaches_all_ranks(limited_rank, tmp_gsd):
+    check_batched(run_ranks(tmp_gsd, 2, limited_rank, device=False, batched=True), limited_rank)
+
+
+@pytest.mark.gpu
+def test_device_write_failure_with_batched_frame_exchange_two_ranks(tmp_gsd):
+    check_batched(run_ranks(tmp_gsd, 2, 1, device=True, batched=True), 1, device=True)

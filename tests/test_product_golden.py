@@ -20,6 +20,23 @@ def test_product_matches_reference_file(name, P, tmp_gsd):
     assert log == S.read_log(golden[:-4] + ".log")
 
 
+@pytest.mark.parametrize("name,P", S.golden_cases())
+def test_product_with_batched_frame_exchange_matches_reference_file(name, P, tmp_gsd, tmp_path):
+    """pgsd_set_frame_exchange(1): small replicated chunks are queued and ONE allgather per frame places them
+    (the device chunks of the GPU tests likewise) -- the file and the state trace must not change by a byte."""
+    scn = product.batched_script(S.scenario_path(name), str(tmp_path / "batched.scn"))
+    log = product.run_driver(scn, tmp_gsd, P)
+    golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        mine, ref = f.read(), g.read()
+    assert len(mine) == len(ref)
+    assert mine == ref
+    # `batch` lines shift the line numbers the driver prints: compare the trace without them
+    import re
+    strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines]
+    assert strip(log) == strip(S.read_log(golden[:-4] + ".log"))
+
+
 MPIEXEC = "/opt/conda/bin/mpiexec"
 MPI_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_mpi")
 
