@@ -16,13 +16,16 @@ import pgsd.fl as fl
 class MirrorComm:
     """rank 0 of 2; the peer mirrors rank 0's contribution"""
 
-    def __init__(self):
+    def __init__(self, peer_empty=False):
         self.calls = []
 
         def allgather(ctx, send, recv, nbytes):
             self.calls.append(nbytes)
             ctypes.memmove(recv, send, nbytes)
             ctypes.memmove(recv + nbytes, send, nbytes)
+            if peer_empty and nbytes > 16:
+                # a frame exchange [status, count, sizes...]: the peer made the same calls with no rows
+                ctypes.memset(recv + nbytes + 16, 0, nbytes - 16)
             return 0
 
         self._ag = _lib.ALLGATHER_FN(allgather)
@@ -120,12 +123,20 @@ def test_mirror_lags_until_the_exchange(tmp_gsd):
     f.close()
 
 
+@pytest.fixture
+def empty_peer():
+    m = MirrorComm(peer_empty=True)
+    yield m
+    m.close()
+
+
 @pytest.mark.gpu
-def test_one_collective_per_device_frame(mirror, tmp_gsd):
+def test_one_collective_per_device_frame(empty_peer, tmp_gsd):
     """The bench / HOOMD-SPH frame: a replicated step chunk, three per-particle chunks packed by one fused
     launch with the partition taken from the exchange, end_frame -- ONE allgather (it goes out after the
     pack launch, so on the RCCL back end the ncclAllGather overlaps the kernel)."""
     torch = pytest.importorskip("torch")
+    mirror = empty_peer
     N = 5000
     pos = torch.randn((N, 4), device="cuda")
     vel = torch.randn((N, 4), device="cuda")
@@ -144,8 +155,9 @@ def test_one_collective_per_device_frame(mirror, tmp_gsd):
     f.close()
     g = fl.open(tmp_gsd, "r")
     got = g.read_chunk(2, "particles/position")
-    assert got.shape == (2 * N, 3)                      # the mirrored peer "owns" the second half
-    np.testing.assert_array_equal(got[:N], pos[:, :3].cpu().numpy())
+    assert got.shape == (N, 3)                          # the peer made the same calls with no rows of its own
+    np.testing.assert_array_equal(got, pos[:, :3].cpu().numpy())
+    assert g.read_chunk(1, "configuration/step")[0] == 1
     g.close()
 
 

@@ -94,6 +94,7 @@ def make_jobs(workload, N, gen):
     return jobs, algo, moved, keep
 
 
+KERNEL_ONLY = False
 AB_KEYS = ("PGSD_PACK_VARIANT", "PGSD_PACK_KERNEL", "PGSD_PACK_ROWS_CFG", "PGSD_PACK_TILE", "PGSD_PACK_BLOCKS_PER_CU")
 
 
@@ -129,6 +130,7 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     import time
+    kernel_ms = []
     for i in range(iters):
         arr, n, _ = sets[i % n_sets]
         if sleep_ms > 0:
@@ -146,10 +148,16 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
             else:
                 os.environ["PGSD_PACK_VARIANT"] = v
         evs[i][0].record()
-        _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
+        if KERNEL_ONLY:
+            # the dispatches' own begin / end stamps (what rocprofv3 reports): no launch latency in the figure
+            ms = ctypes.c_float(0)
+            assert _lib.lib.pgsd_pack_fields_timed(n, arr, N, ctypes.c_void_p(stream), ctypes.byref(ms)) == 0
+            kernel_ms.append(ms.value)
+        else:
+            _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
         evs[i][1].record()
     torch.cuda.synchronize()
-    ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    ts = np.array(kernel_ms if KERNEL_ONLY else [a.elapsed_time(b) for a, b in evs]) * 1e-3
     if variants:
         out = {"workload": workload, "N": N, "interleaved": True}
         for k, v in enumerate(variants):
@@ -159,7 +167,7 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
     med, mn = float(np.median(ts)), float(ts.min())
     return {"workload": workload, "N": N, "sets": n_sets, "median_us": round(med * 1e6, 2), "min_us": round(mn * 1e6, 2),
             "algo_GBps": round(algo / med / 1e9, 1), "moved_GBps": round(moved / med / 1e9, 1),
-            "frac_algo": round(algo / med / 8e12, 4), "env": {k: v for k, v in os.environ.items() if k.startswith("PGSD_PACK")}}
+            "frac_algo": round(algo / med / 8e12, 4), "timing": "kernel" if KERNEL_ONLY else "stream events", "env": {k: v for k, v in os.environ.items() if k.startswith("PGSD_PACK")}}
 
 
 if __name__ == "__main__":
@@ -171,7 +179,11 @@ if __name__ == "__main__":
     ap.add_argument("--sleep-ms", type=float, default=0.0)
     ap.add_argument("--variants", default="", help="comma list of variants to interleave launch by launch: a "
                     "PGSD_PACK_VARIANT value, or KEY=VALUE[+KEY=VALUE] settings of the PGSD_PACK_* variables")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="time with the dispatches' own stamps (pgsd_pack_fields_timed) instead of stream events "
+                         "around the call")
     a = ap.parse_args()
+    KERNEL_ONLY = a.kernel_only
     for w in a.workloads.split(","):
         r = run(w, a.N, a.iters, a.warmup, a.sleep_ms, [v for v in a.variants.split(',') if v] or None)
         r['sleep_ms'] = a.sleep_ms
