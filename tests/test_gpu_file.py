@@ -127,7 +127,7 @@ def test_fused_device_write_matches_oracle(N, tmp_path):
     g.close()
 
 
-def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False):
+def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False, batched=False):
     try:
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,6 +141,7 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False):
         n = counts[rank]
         row0 = int(sum(counts[:rank]))
         f = fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+        f.frame_exchange = batched      # batched: ONE exchange per frame, the partition derived from it
         for frame in range(2):
             pos = S.gen_data(9, seed + frame, row0, n, 4)
             tid = S.gen_data(3, seed + frame, row0, n, 1)
@@ -149,8 +150,10 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False):
             f.write_chunk('configuration/step', np.array([frame], dtype=np.uint64), write_all=False)
             f.write_chunks([('particles/position', fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
                             ('particles/typeid', fl.DeviceField.from_tensor(dtid, out_dtype=np.uint32))],
-                           offset=np.array(counts), rank=rank)
+                           offset="auto" if batched else np.array(counts), rank=rank)
             f.end_frame(wait=not async_seal)
+        if batched:
+            assert f.collective_count <= 2 + 2 + 1     # create/open, one per frame, the barrier of close (counted after)
         f.close()
         _lib.lib.pgsd_comm_finalize()
         q.put((rank, "ok"))
@@ -160,9 +163,10 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False):
         raise
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("async_seal", [False, True])
 @pytest.mark.parametrize("counts", [[600, 401], [0, 333, 1]])
-def test_multi_rank_device_write_matches_oracle(counts, async_seal, tmp_path):
+def test_multi_rank_device_write_matches_oracle(counts, async_seal, batched, tmp_path):
     """P processes share cuda:0 (<= 3 ranks), talk through the shm communicator, each packs
     and writes its own partition; the file equals the oracle's P-rank file."""
     P = len(counts)
@@ -171,7 +175,7 @@ def test_multi_rank_device_write_matches_oracle(counts, async_seal, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     shm = "pgsdgpu_%s" % uuid.uuid4().hex[:10]
-    procs = [ctx.Process(target=_rank_main, args=(r, P, shm, mine, counts, seed, q, async_seal)) for r in range(P)]
+    procs = [ctx.Process(target=_rank_main, args=(r, P, shm, mine, counts, seed, q, async_seal, batched)) for r in range(P)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

@@ -21,16 +21,21 @@ def asan_driver():
     return ASAN_DRIVER
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("name,P", [("sph_full", 4), ("index_expand", 2), ("names_reloc", 5), ("maxbuf", 4),
-                                    ("reopen", 2), ("midflush", 3), ("zero_rank", 8), ("alltypes", 1)])
-def test_scenarios_are_sanitizer_clean(asan_driver, name, P, tmp_path):
+                                    ("reopen", 2), ("midflush", 3), ("zero_rank", 8), ("alltypes", 1),
+                                    ("defaultargs", 3)])
+def test_scenarios_are_sanitizer_clean(asan_driver, name, P, batched, tmp_path):
     out = str(tmp_path / "out.gsd")
+    script = S.scenario_path(name)
+    if batched:     # the queue / frame exchange of pgsd_set_frame_exchange under the sanitizers as well
+        script = product.batched_script(script, str(tmp_path / "batched.scn"))
     shm = "pgsdasan_%s" % uuid.uuid4().hex[:10]
     procs = []
     for r in range(P):
         env = dict(os.environ, PGSD_RANK=str(r), PGSD_NRANKS=str(P), PGSD_SHM_NAME=shm,
                    ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-        procs.append(subprocess.Popen([asan_driver, S.scenario_path(name), out], env=env,
+        procs.append(subprocess.Popen([asan_driver, script, out], env=env,
                                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
     reports = []
     for p in procs:

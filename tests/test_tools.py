@@ -82,3 +82,50 @@ def test_vtu_export_round_trip(tmp_path):
         xml.dom.minidom.parseString(head)      # the XML part is well formed
     with pytest.raises(ValueError):
         vtu.write_vtu(str(tmp_path / "bad.vtu"), np.zeros((3, 2)))
+
+
+def _vtk_spec_reader(path):
+    """A reader written from the VTK XML file-format description, independent of pgsd.vtu: the XML part is
+    parsed with ElementTree; appended raw data starts behind the '_' that follows the <AppendedData> tag, every
+    DataArray's `offset` counts from there, each block is a header_type (UInt64) byte count + the bytes."""
+    import struct
+    import xml.etree.ElementTree as ET
+    raw = open(path, "rb").read()
+    at = raw.index(b"<AppendedData")
+    start = raw.index(b"_", raw.index(b">", at)) + 1
+    root = ET.fromstring(raw[:at] + b"</VTKFile>")
+    assert root.attrib["type"] == "UnstructuredGrid" and root.attrib["byte_order"] == "LittleEndian"
+    assert root.attrib["header_type"] == "UInt64"
+    np_of = {"Float32": "<f4", "Float64": "<f8", "Int32": "<i4", "UInt32": "<u4", "Int64": "<i8", "UInt64": "<u8",
+             "UInt8": "u1", "Int8": "i1"}
+    piece = root.find("UnstructuredGrid/Piece")
+    arrays = {"_npoints": int(piece.attrib["NumberOfPoints"]), "_ncells": int(piece.attrib["NumberOfCells"])}
+    for da in root.iter("DataArray"):
+        assert da.attrib["format"] == "appended"
+        off = start + int(da.attrib["offset"])
+        nbytes = struct.unpack_from("<Q", raw, off)[0]
+        a = np.frombuffer(raw, dtype=np_of[da.attrib["type"]], count=nbytes // np.dtype(np_of[da.attrib["type"]]).itemsize,
+                          offset=off + 8)
+        nc = int(da.attrib["NumberOfComponents"])
+        arrays[da.attrib["Name"]] = a.reshape(-1, nc) if nc > 1 else a
+    return arrays
+
+
+def test_vtu_files_hold_the_frames_values_for_an_independent_reader(tmp_path):
+    """The exported numbers, read back by a parser that shares no code with the exporter: points, every
+    per-particle field, one VTK_VERTEX cell per particle (connectivity i, offsets i+1, type 1)."""
+    import pgsd.vtu as vtu
+    path = str(tmp_path / "run.gsd")
+    frames = _write_traj(path, N=257, frames=2)
+    files = vtu.pgsd2vtu(path, out_dir=str(tmp_path / "vtk"))
+    for fr, name in zip(frames, files):
+        got = _vtk_spec_reader(name)
+        assert got["_npoints"] == got["_ncells"] == 257
+        np.testing.assert_array_equal(got["points"], fr.particles.position)
+        np.testing.assert_array_equal(got["velocity"], fr.particles.velocity)
+        np.testing.assert_array_equal(got["typeid"], fr.particles.typeid)
+        np.testing.assert_array_equal(got["density"], fr.particles.density)
+        np.testing.assert_array_equal(got["connectivity"], np.arange(257))
+        np.testing.assert_array_equal(got["offsets"], np.arange(1, 258))
+        assert (got["types"] == 1).all()                      # VTK_VERTEX
+        assert int(got["step"][0]) == fr.configuration.step

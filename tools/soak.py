@@ -17,6 +17,8 @@ path = "/dev/shm/pgsd_soak_%d.gsd" % os.getpid()
 pos = torch.randn((N, 4), device="cuda")
 vel = torch.randn((N, 4), device="cuda")
 f = fl.open(path, "w", application="soak", schema="hoomd", schema_version=[1, 4])
+batched = len(sys.argv) > 3 and sys.argv[3] == "batched"
+f.frame_exchange = batched                                 # one exchange per frame, chunks staged then placed
 t0 = time.perf_counter()
 marks = []
 for i in range(frames):
@@ -25,7 +27,7 @@ for i in range(frames):
     f.write_chunks([("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
                     ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
                     ("particles/typeid", fl.DeviceField.from_tensor(pos, columns=(3, 4), out_dtype=np.uint32, bitcast=True))],
-                   offset=np.array([N]))
+                   offset="auto" if batched else np.array([N]))
     f.end_frame(wait=False)
     f.wait_packed()
     if i % (frames // 10) == 0:
