@@ -3,14 +3,16 @@
 // The counterpart of the reference's pgsd/scripts/benchmark-write.cc for this library: every
 // rank (one process per GPU; ranks meet through the shm communicator or stay alone) holds
 // HOOMD-style Scalar4 arrays in HBM, and per frame calls
-//   pgsd_partition_rows  -> row offsets (the MPI_Allgather of benchmark-write.cc:39-45)
-//   pgsd_write_chunk     -> configuration/step (replicated small chunk)
-//   pgsd_write_chunks_device -> position, velocity, typeid in one fused pack launch
-//   pgsd_end_frame
-// and prints MB/s the way the reference's benchmark does, as one JSON line on rank 0.
+//   pgsd_write_chunk     -> configuration/step (replicated small chunk; queued)
+//   pgsd_write_chunks_device(..., PGSD_PARTITION_AUTO) -> position, velocity, typeid in one fused pack
+//                           launch (queued: the kernel runs, the file offsets come with the exchange)
+//   pgsd_end_frame       -> ONE allgather of the ranks' chunk sizes (it also yields the row partition, the
+//                           MPI_Allgather of benchmark-write.cc:39-45), placement, copies, writes, index
+// (pgsd_set_frame_exchange; pass "perchunk" as 4th argument for one exchange per chunk and the caller-side
+// pgsd_partition_rows instead) and prints MB/s the way the reference's benchmark does, as one JSON line on rank 0.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file]
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [perchunk]
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -49,6 +51,7 @@ int main(int argc, char** argv)
     const uint64_t n = argc > 1 ? strtoull(argv[1], NULL, 10) : 10000000ull;
     const int frames = argc > 2 ? atoi(argv[2]) : 10;
     const char* path = argc > 3 ? argv[3] : "/dev/shm/pgsd_benchmark_write.gsd";
+    const bool batched = !(argc > 4 && strcmp(argv[4], "perchunk") == 0);
     CHECK(pgsd_comm_init_from_env());
     const int rank = pgsd_comm_rank(), P = pgsd_comm_size();
     int ndev = 0;
@@ -85,11 +88,16 @@ int main(int argc, char** argv)
     req[2].M = 1;
     req[2].src = {pos, NULL, PGSD_TYPE_FLOAT, 4, 3, 1};
 
+    CHECK(pgsd_set_frame_exchange(&h, batched ? 1 : 0));
     auto frame = [&](uint64_t step) -> int
     {
-        CHECK(pgsd_partition_rows(n, &row0, &n_global, NULL));
+        if (!batched)
+            CHECK(pgsd_partition_rows(n, &row0, &n_global, NULL));
         CHECK(pgsd_write_chunk(&h, "configuration/step", PGSD_TYPE_UINT64, 1, 1, 1, 1, 0, 1, false, 0, &step));
-        CHECK(pgsd_write_chunks_device(&h, 3, req, n, n_global, row0));
+        if (batched)
+            CHECK(pgsd_write_chunks_device(&h, 3, req, n, PGSD_PARTITION_AUTO, 0));
+        else
+            CHECK(pgsd_write_chunks_device(&h, 3, req, n, n_global, row0));
         CHECK(pgsd_end_frame(&h));
         return 0;
     };
@@ -104,13 +112,16 @@ int main(int argc, char** argv)
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     struct pgsd_device_stats st;
     pgsd_device_get_stats(&h, &st, 0);
+    const unsigned long long collectives = (unsigned long long)pgsd_get_collective_count(&h);
     CHECK(pgsd_close(&h));
     if (rank == 0)
         {
         printf("{\"ranks\": %d, \"particles_per_rank\": %llu, \"frames\": %d, \"seconds\": %.4f, \"MBps\": %.1f, "
-               "\"pack_launches\": %llu, \"written_bytes_rank0\": %llu}\n",
+               "\"pack_launches\": %llu, \"written_bytes_rank0\": %llu, \"exchange\": \"%s\", "
+               "\"collectives_rank0\": %llu}\n",
                P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
-               (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes);
+               (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes,
+               batched ? "one per frame" : "one per chunk", collectives);
         unlink(path);
         }
     pgsd_comm_finalize();

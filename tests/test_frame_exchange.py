@@ -177,3 +177,31 @@ def test_a_handle_keeps_its_communicator_alive_across_finalize(mirror, tmp_gsd):
     g = fl.open(tmp_gsd, "r")                          # a new handle sees the new (single-rank) default
     assert g.nframes == 2 and g.read_chunk(1, "particles/position").shape == (8, 3)
     g.close()
+
+
+@pytest.mark.gpu
+def test_async_frames_do_not_pin_their_source_tensors(tmp_gsd):
+    """A long run of end_frame(wait=False) without frame_sync: only the newest frames' device fields are kept
+    alive (their pack kernels may still read them); older ones are released, synchronous calls release all."""
+    torch = pytest.importorskip("torch")
+    N = 2000
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    import weakref
+    refs = []
+    for i in range(12):
+        t = torch.randn((N, 4), device="cuda")
+        refs.append(weakref.ref(t))
+        f.write_chunks([("particles/position", fl.DeviceField.from_tensor(t, columns=(0, 3)))], offset=np.array([N]))
+        f.end_frame(wait=False)
+        del t
+    import gc
+    gc.collect()
+    assert len(f._PGSDFile__async_keep) <= 2
+    assert sum(r() is not None for r in refs) <= 2
+    f.flush()
+    gc.collect()
+    assert not f._PGSDFile__async_keep and all(r() is None for r in refs)
+    f.close()
+    g = fl.open(tmp_gsd, "r")
+    assert g.nframes == 12
+    g.close()
