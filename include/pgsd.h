@@ -206,10 +206,10 @@ extern "C"
        (pgsd.c:2157, 2242) as one 16-byte allgather -- so handle->file_size is current after each call,
        and pgsd_end_frame ends with a status exchange that doubles as the barrier after which every
        rank's rows of the frame are in the file.
-       On: chunk writes that do not need their file offset at once are QUEUED: replicated chunks below
-       the write-buffer limit (copied) and all device chunks (packed into the staging arena at once,
+       On: chunk writes that do not need their file offset at once are QUEUED: replicated host chunks
+       (all == false; copied) and all device chunks (packed into the staging arena at once,
        the kernel needs no offset).  ONE allgather at the next pgsd_end_frame (or pgsd_flush,
-       pgsd_close, a read, a host per-particle chunk, a buffer-limit setter) carries every rank's
+       pgsd_close, a read, a host chunk with all == true, a buffer-limit setter) carries every rank's
        status word and the byte counts of all queued chunks; placement then replays the reference's
        decisions in call order, so the file is byte-identical to the unbatched one.  A frame of
        small chunks + device chunks + pgsd_end_frame costs ONE collective (one ncclAllGather on the

@@ -1039,21 +1039,34 @@ static int resolve_queue(Impl* s)
     if (s->P > 1)
         {
         recv.assign((k + 2) * (size_t)s->P, 0);
-        if (s->gather(send.data(), recv.data(), send.size() * sizeof(uint64_t)) != 0)
-            {
+        bool comm_ok = s->gather(send.data(), recv.data(), send.size() * sizeof(uint64_t)) == 0;
+        if (!comm_ok)
             set_last_error("communicator allgather failed");
-            return PGSD_ERROR_COMM; // the queue stays: nothing sane can be placed
+        for (int r = 0; r < s->P && comm_ok; r++)
+            if (recv[(size_t)r * (k + 2) + 1] != k)
+                {
+                set_last_error("the ranks queued different numbers of chunks for this frame");
+                comm_ok = false;
+                }
+        if (!comm_ok)
+            {
+            // Nothing sane can be placed any more.  The queue is dropped (its borrowed row pointers die
+            // with this call, packed device chunks are released) and the failure stays with the handle.
+            std::vector<Queued> dead;
+            dead.swap(s->queue);
+            Placement none;
+            memset(&none, 0, sizeof(none));
+            for (Queued& q : dead)
+                if (q.ticket >= 0)
+                    (void)deliver_chunk(s, q, none, true);
+            remember_failure(s, PGSD_ERROR_COMM, 0);
+            return PGSD_ERROR_COMM;
             }
         s->sticky_rc = PGSD_SUCCESS; // shared now
         s->sticky_errno = 0;
         for (int r = 0; r < s->P; r++)
             {
             const uint64_t* v = recv.data() + (size_t)r * (k + 2);
-            if (v[1] != k)
-                {
-                set_last_error("the ranks queued different numbers of chunks for this frame");
-                return PGSD_ERROR_COMM;
-                }
             const int src = (int)(int32_t)(uint32_t)v[0];
             if (src != PGSD_SUCCESS && first_rc == PGSD_SUCCESS)
                 {
@@ -1350,9 +1363,9 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
     const int local = check_chunk_args(s, name, N, M, flags, data != NULL);
     if (s->batch)
         {
-        // frame-batched exchange: a replicated chunk below the buffer limit waits (with a copy of its
-        // rows) for the frame's exchange; a chunk that needs its file offset now -- per-particle rows,
-        // or more bytes than the buffer takes -- resolves the queue, itself included, at once
+        // frame-batched exchange: a replicated chunk (all == false) waits, with a copy of its rows, for
+        // the frame's exchange; per-particle rows (all == true) are borrowed for the call only and need
+        // their file offset now: they resolve the queue, themselves included, at once
         Queued q;
         q.name = name ? name : "";
         q.type = (uint32_t)type;
@@ -1360,11 +1373,14 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
         q.local_rc = local;
         const uint64_t size = local == PGSD_SUCCESS ? N * M * sizeof_type((uint32_t)type) : 0;
         int rc = local;
-        if (local == PGSD_SUCCESS && (all || size >= s->maxbuf))
+        // Which of the two it is must not depend on anything a single rank sees differently (its
+        // argument check, its byte count): `all` is the caller's flag, the same on every rank.
+        if (all)
             {
-            q.borrowed = data;
+            q.borrowed = local == PGSD_SUCCESS ? data : nullptr;
             s->queue.push_back(std::move(q));
-            rc = resolve_queue(s);
+            const int qrc = resolve_queue(s);
+            rc = local != PGSD_SUCCESS ? local : qrc;
             }
         else
             {

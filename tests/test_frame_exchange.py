@@ -205,3 +205,64 @@ def test_async_frames_do_not_pin_their_source_tensors(tmp_gsd):
     g = fl.open(tmp_gsd, "r")
     assert g.nframes == 12
     g.close()
+
+
+def _bad_args_rank(rank, shm, path, batched, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
+        from pgsd import _lib as L
+        import pgsd.fl as F
+        assert L.lib.pgsd_comm_init_shm(shm.encode(), rank, 2) == 0
+        f = F.open(path, "w", application="app", schema="hoomd", schema_version=[1, 4])
+        f.frame_exchange = batched
+        h = f._h()
+        data = np.arange(15, dtype=np.float32)
+        out = []
+        # rank 1 passes M = 0 (pgsd.c:2096-2099: invalid argument) for a per-particle chunk, rank 0 is fine
+        M = 0 if rank == 1 else 3
+        out.append(L.lib.pgsd_write_chunk(h, b"particles/position", 9, 5, M, 10, M, 5 * rank * 3, 30, True, 0,
+                                          data.ctypes.data))
+        # ... and a NULL data pointer for a replicated chunk
+        ptr = None if rank == 1 else data.ctypes.data
+        out.append(L.lib.pgsd_write_chunk(h, b"log/x", 9, 3, 1, 3, 1, 0, 3, False, 0, ptr))
+        out.append(L.lib.pgsd_end_frame(h))
+        # the next frame is healthy on both ranks
+        f.write_chunk("particles/position", data.reshape(5, 3), offset="auto")
+        f.end_frame()
+        ok = f.chunk_exists(1, "particles/position") and not f.chunk_exists(0, "particles/position")
+        f.close()
+        L.lib.pgsd_comm_finalize()
+        q.put((rank, out, bool(ok)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), False))
+        raise
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_bad_arguments_on_one_rank_fail_the_call_everywhere_without_a_hang(batched, tmp_gsd):
+    """The reference returns from its argument checks before the first collective (pgsd.c:2090-2105): the
+    rank with the bad argument leaves, the others wait in MPI_Barrier for ever.  Here the verdict travels with
+    the size exchange: the per-particle chunk fails on BOTH ranks, in either exchange mode, nothing hangs and
+    the file goes on."""
+    import multiprocessing as mp
+    import uuid
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = "pgsdbad_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_bad_args_rank, args=(r, shm, tmp_gsd, batched, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    for rank, out, ok in results:
+        assert isinstance(out, list), out
+        assert out[0] == -2, (rank, out)                      # PGSD_ERROR_INVALID_ARGUMENT on both ranks
+        assert ok, (rank, out)
+    # the replicated chunk: the rank with the NULL pointer knows at once; everyone by the end of the frame
+    r0, r1 = results[0][1], results[1][1]
+    assert r1[1] == -2 and (r0[1] == -2 or r0[2] == -2)
