@@ -697,12 +697,52 @@ __device__ __forceinline__ void row_emit(const RowsOut& o, const RowRegs& r, uin
     row_store<NWMAX>((uint32_t*)o.dst + i * nw, w, nw);
     }
 
-// Row mode: blockIdx.y = source array (group), blockIdx.x = block of T*U consecutive rows.  The
-// dispatcher walks x fastest, so the launch streams array after array (group-major).
+// Dense chunks of the source's own type (the chunk IS the array: scalar arrays, orientation, ...): 16 bytes
+// per lane.  The gridDim.x workgroups of the array share its vectors evenly, one contiguous slice each,
+// whatever the array's length relative to the row-mode arrays of the same launch.
+template<int T, int U> __device__ __forceinline__ void copy_body(const RowsGroup& g)
+    {
+    const u32x4* src = (const u32x4*)g.src;
+    u32x4* dst = (u32x4*)g.out[0].dst;
+    const uint64_t nvec = g.copy_vecs;
+    const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * per;
+    const uint64_t last = first + per < nvec ? first + per : nvec;
+    for (uint64_t base = first + threadIdx.x; base < last; base += (uint64_t)(T * U))
+        {
+        u32x4 r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t v = base + (uint64_t)k * T;
+            if (v < last)
+                r[k] = __builtin_nontemporal_load(src + v);
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t v = base + (uint64_t)k * T;
+            if (v < last)
+                __builtin_nontemporal_store(r[k], dst + v);
+            }
+        }
+    if (blockIdx.x == 0 && threadIdx.x < g.copy_tail)
+        ((char*)dst)[nvec * 16 + threadIdx.x] = ((const char*)src)[nvec * 16 + threadIdx.x];
+    }
+
+// blockIdx.y = source array (group), blockIdx.x = block of T*U consecutive rows (or 16-byte vectors of a
+// dense array riding along in the same launch).  The dispatcher walks x fastest, so the launch streams
+// array after array (group-major); ONE launch per frame keeps small snapshots from paying a second
+// launch's ramp (2^20 particles with a separate id array: 16.5 us as two launches, see profiles/).
 template<int T, int U, int RW, bool BITS_ONLY>
 __global__ __launch_bounds__(T) void pack_rows_kernel(const RowsArgs args)
     {
     const RowsGroup& g = args.g[blockIdx.y];
+    if (g.copy_vecs != 0 || g.copy_tail != 0)
+        {
+        copy_body<T, U>(g);
+        return;
+        }
     RowRegs r[U];
     const uint64_t N = args.N;
     const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
@@ -731,35 +771,10 @@ __global__ __launch_bounds__(T) void pack_rows_kernel(const RowsArgs args)
         }
     }
 
-// Copy mode: dense chunks of the source's own type (the chunk IS the array: scalar arrays,
-// orientation, ...), 16 bytes per lane.  blockIdx.y = array, arrays shorter than the longest one of
-// the launch leave their surplus workgroups at once.
+// a launch of dense arrays only
 template<int T, int U> __global__ __launch_bounds__(T) void pack_copy_kernel(const RowsArgs args)
     {
-    const RowsGroup& g = args.g[blockIdx.y];
-    const u32x4* src = (const u32x4*)g.src;
-    u32x4* dst = (u32x4*)g.out[0].dst;
-    const uint64_t nvec = g.copy_vecs;
-    const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
-    if (base - threadIdx.x >= nvec && !(blockIdx.x == 0 && g.copy_tail))
-        return;
-    u32x4 r[U];
-#pragma unroll
-    for (int k = 0; k < U; k++)
-        {
-        const uint64_t v = base + (uint64_t)k * T;
-        if (v < nvec)
-            r[k] = __builtin_nontemporal_load(src + v);
-        }
-#pragma unroll
-    for (int k = 0; k < U; k++)
-        {
-        const uint64_t v = base + (uint64_t)k * T;
-        if (v < nvec)
-            __builtin_nontemporal_store(r[k], dst + v);
-        }
-    if (blockIdx.x == 0 && threadIdx.x < g.copy_tail)
-        ((char*)dst)[nvec * 16 + threadIdx.x] = ((const char*)src)[nvec * 16 + threadIdx.x];
+    copy_body<T, U>(args.g[blockIdx.y]);
     }
 
 // Fallback for operands the tiled kernel cannot take (unaligned pointers, very wide
@@ -1294,6 +1309,12 @@ static void launch_rows(const RowsCfg& c, const RowsArgs& a, bool copy, uint32_t
         launch_rows_tu<128, 2>(a, copy, rw, bits_only, stream, e0, e1);
     else if (c.T == 64 && c.U == 2)
         launch_rows_tu<64, 2>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 256 && c.U == 8)
+        launch_rows_tu<256, 8>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 512 && c.U == 4)
+        launch_rows_tu<512, 4>(a, copy, rw, bits_only, stream, e0, e1);
+    else if (c.T == 512 && c.U == 2)
+        launch_rows_tu<512, 2>(a, copy, rw, bits_only, stream, e0, e1);
     else
         launch_rows_tu<128, 1>(a, copy, rw, bits_only, stream, e0, e1);
     }
@@ -1361,8 +1382,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
     if (const char* e = getenv("PGSD_PACK_KERNEL"))
         kernel = strcmp(e, "waves") == 0 ? K_WAVES : (strcmp(e, "tiles") == 0 ? K_TILES : K_ROWS);
 
-    // 1. the row-per-lane kernels take every job they can: one launch per class of source arrays
-    //    (dense copies | rows of rw dwords), up to PACK_MAX_GROUPS arrays each
+    // 1. the row-per-lane kernel takes every job it can: one launch per class of source-row width (a
+    //    compile-time parameter), dense same-type arrays ride along in any launch; up to ROWS_MAX_GROUPS
+    //    arrays each.  The headline layouts are ONE launch.
     if (kernel == K_ROWS)
         {
         while (true)
@@ -1370,71 +1392,74 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             RowsArgs a;
             memset(&a, 0, sizeof(a));
             a.N = N;
-            bool copy = false, bits_only = true;
-            uint32_t cls_rw = 0;
-            for (uint32_t i = 0; i < n_jobs; i++)
-                {
-                if (done[i])
-                    continue;
-                const pgsd_pack_job& j = jobs[i];
-                uint32_t rk = 0;
-                if (!rows_eligible(j, N, &rk))
-                    continue;
-                const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type), dsz = (uint32_t)sizeof_type(j.dst_type);
-                const uint32_t rw = j.src.src_stride * ssz / 4;
-                const bool dense
-                    = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
-                if (a.n_groups == 0)
+            bool bits_only = true;
+            uint32_t cls_rw = 0; // 0: no row-mode array in this launch yet
+            // row-mode arrays first decide the class, then the dense ones fill the launch up
+            for (int pass = 0; pass < 2; pass++)
+                for (uint32_t i = 0; i < n_jobs; i++)
                     {
-                    copy = dense;
-                    cls_rw = rw;
-                    }
-                else if (dense != copy || (!dense && rw != cls_rw))
-                    continue; // another class: a later launch
-                int gi = -1;
-                if (!dense)
-                    for (uint32_t k = 0; k < a.n_groups; k++)
-                        if (a.g[k].src == j.src.src && a.g[k].order == j.src.order && a.g[k].n_out < PACK_MAX_OUT)
-                            gi = (int)k;
-                if (gi < 0)
-                    {
-                    if (a.n_groups == PACK_MAX_GROUPS)
-                        continue; // next launch
-                    gi = (int)a.n_groups++;
-                    RowsGroup& g = a.g[gi];
-                    g.src = j.src.src;
-                    g.order = j.src.order;
-                    g.row_words = rw;
-                    if (dense)
+                    if (done[i])
+                        continue;
+                    const pgsd_pack_job& j = jobs[i];
+                    uint32_t rk = 0;
+                    if (!rows_eligible(j, N, &rk))
+                        continue;
+                    const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type), dsz = (uint32_t)sizeof_type(j.dst_type);
+                    const uint32_t rw = j.src.src_stride * ssz / 4;
+                    const bool dense
+                        = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
+                    if (dense != (pass == 1))
+                        continue;
+                    if (!dense && cls_rw != 0 && rw != cls_rw)
+                        continue; // another class: a later launch
+                    int gi = -1;
+                    if (!dense)
+                        for (uint32_t k = 0; k < a.n_groups; k++)
+                            if (a.g[k].copy_vecs == 0 && a.g[k].copy_tail == 0 && a.g[k].src == j.src.src
+                                && a.g[k].order == j.src.order && a.g[k].n_out < PACK_MAX_OUT)
+                                gi = (int)k;
+                    if (gi < 0)
                         {
-                        const uint64_t bytes = N * (uint64_t)j.src.src_stride * ssz;
-                        g.copy_vecs = bytes >> 4;
-                        g.copy_tail = (uint32_t)(bytes & 15);
+                        if (a.n_groups == ROWS_MAX_GROUPS)
+                            continue; // next launch
+                        gi = (int)a.n_groups++;
+                        RowsGroup& g = a.g[gi];
+                        g.src = j.src.src;
+                        g.order = j.src.order;
+                        g.row_words = rw;
+                        if (dense)
+                            {
+                            const uint64_t bytes = N * (uint64_t)j.src.src_stride * ssz;
+                            g.copy_vecs = bytes >> 4;
+                            g.copy_tail = (uint32_t)(bytes & 15);
+                            }
+                        else
+                            cls_rw = rw;
                         }
+                    RowsGroup& g = a.g[gi];
+                    RowsOut& o = g.out[g.n_out++];
+                    o.dst = j.dst;
+                    o.col0 = j.src.src_col0 * ssz / 4; // first source dword
+                    o.M = j.M;
+                    o.kind = rk;
+                    o.nw_out = j.M * dsz / 4;
+                    bits_only = bits_only && rk == ROWS_BITS;
+                    done[i] = true;
                     }
-                RowsGroup& g = a.g[gi];
-                RowsOut& o = g.out[g.n_out++];
-                o.dst = j.dst;
-                o.col0 = j.src.src_col0 * ssz / 4; // first source dword
-                o.M = j.M;
-                o.kind = rk;
-                o.nw_out = j.M * dsz / 4;
-                bits_only = bits_only && rk == ROWS_BITS;
-                done[i] = true;
-                }
             if (a.n_groups == 0)
                 break;
+            const bool copy_only = cls_rw == 0;
             const RowsCfg cfg = rows_config(N, a.n_groups);
             const uint64_t per_block = (uint64_t)cfg.T * cfg.U;
             uint64_t blocks = 1;
             for (uint32_t k = 0; k < a.n_groups; k++)
                 {
-                const uint64_t units = copy ? a.g[k].copy_vecs : N;
+                const uint64_t units = (a.g[k].copy_vecs || a.g[k].copy_tail) ? a.g[k].copy_vecs : N;
                 blocks = std::max(blocks, (units + per_block - 1) / per_block);
                 }
-            a.n_blocks = blocks; // N < 2^40 rows (rows_eligible) keeps this below 2^31
+            a.n_blocks = blocks; // N < 2^31 rows (rows_eligible) keeps the grid's x extent below 2^32 threads
             launches.push_back([=](hipEvent_t e0, hipEvent_t e1)
-                               { launch_rows(cfg, a, copy, cls_rw, bits_only, stream, e0, e1); });
+                               { launch_rows(cfg, a, copy_only, cls_rw, bits_only, stream, e0, e1); });
             }
         }
 

@@ -84,6 +84,7 @@ struct PackArgs
 enum
     {
     ROWS_MAX_WORDS = 8, // a source row / a chunk row is at most 8 dwords (double4, N x 4 doubles)
+    ROWS_MAX_GROUPS = 16, // source arrays per launch (16 x 184 B of descriptors: inside the 4 KiB of kernel arguments)
     ROWS_BITS = 0,      // dwords moved unchanged (equal element sizes; 8-byte elements are dword pairs)
     ROWS_F64_F32 = 1,   // f64 -> f32, round to nearest even
     ROWS_F32_F64 = 2    // f32 -> f64
@@ -116,8 +117,9 @@ struct RowsArgs
     uint64_t n_blocks;     // gridDim.x: blocks of T*U rows (or 16-byte vectors); gridDim.y = n_groups
     uint32_t n_groups;
     uint32_t pad;
-    RowsGroup g[PACK_MAX_GROUPS];
+    RowsGroup g[ROWS_MAX_GROUPS];
     };
+static_assert(sizeof(RowsArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 struct PackGenericArgs
     {
