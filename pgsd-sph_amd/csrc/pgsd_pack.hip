@@ -9,20 +9,23 @@
 //          workgroup's count, a one-block scan turns counts into offsets (= per-chunk row
 //          and byte counts), a scatter pass writes the index list.
 //
-// The path is pure data movement, so the design target is the HBM roofline, not MFMA:
-//   * every global access is a 16-byte-per-lane, fully coalesced vector access: a source
-//     tile (TILE rows x row bytes, contiguous in memory) is streamed linearly into LDS,
-//     the re-packed / converted chunk tile is streamed linearly out of it.  The 4->3
-//     component repack, column selection and dtype conversion happen between LDS and
-//     registers, where bandwidth is ~25x the per-CU share of HBM.
+// The path is pure data movement, so the design target is the HBM roofline, not MFMA.  Two families:
+//
+//   row-per-lane (pack_rows_kernel, the default for 4- and 8-byte elements): lane i loads row i of a
+//     source array and stores each chunk's M elements as one contiguous piece at row i of the chunk.  No
+//     LDS, no barrier; every wave instruction covers one contiguous span of whole 128-byte lines (1 KiB
+//     loads, 768-byte / 256-byte stores).  One launch per frame: blockIdx.y = source array, dense
+//     same-type arrays ride along as 16-byte-per-lane copies.  Runs at the rate of a bare register float4
+//     copy of the same bytes (tools/pack_lab.hip, profiles/r02_*).
+//   LDS-tiled (pack_tiles_kernel and its variants, round 1): a source tile (contiguous in memory) is
+//     streamed into LDS with 16-byte-per-lane loads, re-packed / converted between LDS and registers and
+//     streamed out with 16-byte-per-lane stores.  Takes what the row kernel does not: 1- and 2-byte
+//     elements, integer <-> float conversions, gathers through a permutation, rows wider than 32 bytes;
+//     the unpack of the read path is of this family.
 //   * fields that read the same source array (position.xyz and the type id HOOMD keeps
-//     in position.w) form one group: the tile is fetched from HBM once.
-//   * 64-wide wavefronts, 256-thread workgroups, tiles of 1024 rows: all source arrays of a tile
-//     are staged before ONE barrier (16-40 KiB of LDS per workgroup, bank-skewed image), the
-//     grid is min(tiles, 4 workgroups per CU x 256 CUs, LDS residency) and strides over tiles so
-//     that the resident workgroups stream one contiguous window of every array.
-//   * source tiles are read once and chunk tiles written once: non-temporal hints keep
-//     them from displacing each other in L2.
+//     in position.w) form one group: the array is fetched from HBM once.
+//   * 64-wide wavefronts, 256-thread workgroups; source rows are read once and chunk rows written once:
+//     non-temporal hints on both sides (each worth 4-6 % at 10 M particles).
 //
 // No reference counterpart exists (the reference has no device code); the
 // outputs are pinned by oracle_pack_rows() in oracle/pgsd_oracle.c and by the byte layout

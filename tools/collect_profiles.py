@@ -17,8 +17,9 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def first(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
-    return hits[0] if hits else None
+    # gpurun merges new outputs into the directory without removing older ones: take the newest
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None
 
 
 def pack_rows(path, counter=None):
