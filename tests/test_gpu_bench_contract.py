@@ -1,0 +1,55 @@
+"""bench.py's output contract (the driver parses ONE JSON line): required keys, types and the roofline /
+cpu_baseline objects, on a small workload so that it runs in seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--particles", "300000"] + list(extra), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout          # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contracts_fields():
+    d = run_bench("--traffic", "off")
+    assert d["metric"] == "snapshot pack+write GB/s at 10M particles/GPU" and d["unit"] == "GB/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert isinstance(d["value"], float) and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["comm_backend"] == "self" and d["collectives_per_frame"] == 0.0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_bytes_per_launch"] == 56 * 300000 and r["kernel"] == "pack_rows_kernel"
+    assert r["traffic"] is None                     # --traffic off
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "GB/s" and c["value"] > 0
+    assert isinstance(c["sample"], str) and "particles" in c["sample"]
+
+
+def test_bench_measures_its_hbm_traffic_with_the_pmc_counters():
+    """roofline.traffic comes from two rocprofv3 counter passes of the run itself: read bytes = FETCH_SIZE x 2
+    (gfx950), written bytes = WRITE_SIZE; for the row kernel they are the source arrays and the chunks."""
+    d = run_bench("--no-cpu-baseline")
+    r = d["roofline"]
+    if r["traffic"] is None:
+        pytest.skip("rocprofv3 not usable on this box: " + str(r["traffic_source"]))
+    assert r["traffic_source"].startswith("live")
+    n = 300000
+    det = r["traffic_detail"]
+    assert abs(det["write_bytes"] - 28 * n) < 0.02 * 28 * n          # the three chunks
+    assert abs(det["read_bytes"] - 32 * n) < 0.05 * 32 * n           # two float4 arrays
+    assert r["traffic"] == det["read_bytes"] + det["write_bytes"]
