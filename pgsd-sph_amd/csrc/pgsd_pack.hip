@@ -115,48 +115,32 @@ template<int SSZ, int DSZ> __device__ __forceinline__ uint64_t convert_elem(uint
         }
     }
 
-// Variant bits of the streaming kernels (compile-time; the launcher picks one instantiation).
-enum
-    {
-    VAR_GLDS = 1,       // stage linear tiles with LDS-DMA (global_load_lds_dwordx4) instead of VGPRs
-    VAR_PLAIN_LOAD = 2, // default cache policy for source loads instead of non-temporal
-    VAR_PLAIN_STORE = 4, // default cache policy for chunk stores instead of non-temporal
-    VAR_LINEAR_LDS = 8   // no bank skew in the LDS image (A/B switch for the sweeps)
-    };
-
 // LDS image skew: 16 bytes of padding after every 128 bytes.  A staged float4 tile read back
 // column-wise (position.xyz with stride 16/3 words, the w column with stride 16 words) hits the
-// same few of the 32 banks: 6-way conflicts for xyz, 16-way for w in the linear image; with the
+// same few of the 32 banks: 6-way conflicts for xyz, 16-way for w in a linear image; with the
 // skew every 8th row shifts by 4 banks and the worst cases drop to 2- and 4-way
-// (SQ_LDS_BANK_CONFLICT, profiles/).  LDS-DMA writes whole 1 KiB pieces linearly, so that
-// variant keeps the linear image.
-template<int VAR> __device__ __forceinline__ uint32_t lds_skew(uint32_t byte_off)
+// (SQ_LDS_BANK_CONFLICT, profiles/r01_lds_conflicts.md).
+__device__ __forceinline__ uint32_t lds_skew(uint32_t byte_off)
     {
-    if constexpr ((VAR & VAR_GLDS) || (VAR & VAR_LINEAR_LDS))
-        return byte_off;
-    else
-        return byte_off + ((byte_off >> 7) << 4);
+    return byte_off + ((byte_off >> 7) << 4);
     }
 
-template<int VAR> __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+// source tiles are read once and chunk tiles written once: non-temporal on both sides.  (Round 1 swept
+// LDS-DMA staging, default cache policies and a linear LDS image as compile-time variants: none was better,
+// profiles/r01_pack_sweep.jsonl; the variants were removed in round 2.)
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
     {
-    if constexpr (VAR & VAR_PLAIN_LOAD)
-        return *p;
-    else
-        return __builtin_nontemporal_load(p);
+    return __builtin_nontemporal_load(p);
     }
 
-template<int VAR> __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p)
+__device__ __forceinline__ void stream_store(u32x4 v, u32x4* p)
     {
-    if constexpr (VAR & VAR_PLAIN_STORE)
-        *p = v;
-    else
-        __builtin_nontemporal_store(v, p);
+    __builtin_nontemporal_store(v, p);
     }
 
 // Stream the re-packed tile of one output chunk from LDS to global memory:
 // 16 bytes per lane per store, lanes consecutive => each wave store covers 1 KiB.
-template<int SSZ, int DSZ, int NT, int VAR, int KIND = -1>
+template<int SSZ, int DSZ, int NT, int KIND = -1>
 __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uint32_t rows,
                                           uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
@@ -178,7 +162,7 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
 #pragma unroll
         for (uint32_t k = 0; k < EPT; k++)
             {
-            uint64_t raw = lds_load<SSZ>(lds + lds_skew<VAR>((row * stride_elems + col0 + col) * SSZ));
+            uint64_t raw = lds_load<SSZ>(lds + lds_skew((row * stride_elems + col0 + col) * SSZ));
             uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
             if constexpr (DSZ == 8)
                 {
@@ -198,14 +182,14 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
                 }
             }
         u32x4 out = {w[0], w[1], w[2], w[3]};
-        stream_store<VAR>(out, (u32x4*)(gdst + (size_t)v * 16));
+        stream_store(out, (u32x4*)(gdst + (size_t)v * 16));
         }
     // ragged end of the last tile: element-wise
     for (uint32_t e = nvec * EPT + tid; e < nelem; e += NT)
         {
         uint32_t row = (M == 1) ? e : __umulhi(e, o.magic);
         uint32_t col = e - row * M;
-        uint64_t raw = lds_load<SSZ>(lds + lds_skew<VAR>((row * stride_elems + col0 + col) * SSZ));
+        uint64_t raw = lds_load<SSZ>(lds + lds_skew((row * stride_elems + col0 + col) * SSZ));
         uint64_t val = convert_elem<SSZ, DSZ>(raw, kind);
         char* p = gdst + (size_t)e * DSZ;
         if constexpr (DSZ == 8)
@@ -219,20 +203,20 @@ __device__ __forceinline__ void emit_tile(const PackOut& o, const char* lds, uin
         }
     }
 
-template<int SSZ, int NT, int VAR>
+template<int SSZ, int NT>
 __device__ __forceinline__ void emit_dispatch(const PackOut& o, const char* lds, uint32_t rows,
                                               uint32_t stride_elems, uint64_t row0, uint32_t tid)
     {
     switch (o.dsz)
         {
-        case 1: emit_tile<SSZ, 1, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
-        case 2: emit_tile<SSZ, 2, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
-        case 4: emit_tile<SSZ, 4, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
-        default: emit_tile<SSZ, 8, NT, VAR>(o, lds, rows, stride_elems, row0, tid); break;
+        case 1: emit_tile<SSZ, 1, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        case 2: emit_tile<SSZ, 2, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        case 4: emit_tile<SSZ, 4, NT>(o, lds, rows, stride_elems, row0, tid); break;
+        default: emit_tile<SSZ, 8, NT>(o, lds, rows, stride_elems, row0, tid); break;
         }
     }
 
-template<int NT, int MODE, int VAR>
+template<int NT, int MODE>
 __device__ __forceinline__ void emit_group(const PackGroup& g, const char* lds, uint32_t rows, uint64_t row0,
                                            uint32_t tid)
     {
@@ -242,28 +226,28 @@ __device__ __forceinline__ void emit_group(const PackGroup& g, const char* lds, 
         if constexpr (MODE == PACK_MODE_W32)
             {
             // 32-bit words moved unchanged (float4 -> N x 3 float, typeid in position.w, int3 images)
-            emit_tile<4, 4, NT, VAR, PACK_BITS>(o, lds, rows, g.stride, row0, tid);
+            emit_tile<4, 4, NT, PACK_BITS>(o, lds, rows, g.stride, row0, tid);
             continue;
             }
         if constexpr (MODE == PACK_MODE_F64_F32)
             {
             // double4 / double sources written as float32 chunks
-            emit_tile<8, 4, NT, VAR, PACK_F2F>(o, lds, rows, g.stride, row0, tid);
+            emit_tile<8, 4, NT, PACK_F2F>(o, lds, rows, g.stride, row0, tid);
             continue;
             }
         switch (g.ssz)
             {
-            case 1: emit_dispatch<1, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
-            case 2: emit_dispatch<2, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
-            case 4: emit_dispatch<4, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
-            default: emit_dispatch<8, NT, VAR>(o, lds, rows, g.stride, row0, tid); break;
+            case 1: emit_dispatch<1, NT>(o, lds, rows, g.stride, row0, tid); break;
+            case 2: emit_dispatch<2, NT>(o, lds, rows, g.stride, row0, tid); break;
+            case 4: emit_dispatch<4, NT>(o, lds, rows, g.stride, row0, tid); break;
+            default: emit_dispatch<8, NT>(o, lds, rows, g.stride, row0, tid); break;
             }
         }
     }
 
 // Bring `rows` source rows starting at row0 into LDS with NT cooperating lanes:
 // a linear 16-byte-per-lane stream, or a row gather through `order`.
-template<int NT, int VAR>
+template<int NT>
 __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32_t rows, uint64_t row0, uint32_t tid)
     {
     const uint32_t rowbytes = g.rowbytes;
@@ -273,41 +257,25 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
         const char* gsrc = (const char*)g.src + row0 * rowbytes;
         const uint32_t nbytes = rows * rowbytes;
         const uint32_t nvec = nbytes >> 4;
-        if constexpr (VAR & VAR_GLDS)
-            {
-            // LDS-DMA: the 16 bytes of lane l land at (wave-uniform LDS base) + 16*l, so a
-            // linear tile needs no VGPR round trip; the workgroup barrier that follows drains it
-            const uint32_t wave_first = tid & ~63u;
-            for (uint32_t v0 = 0; v0 < nvec; v0 += NT)
-                {
-                const uint32_t v = v0 + tid;
-                if (v < nvec)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)((const u32x4*)gsrc + v),
-                        (__attribute__((address_space(3))) void*)(lds + (size_t)(v0 + wave_first) * 16), 16, 0,
-                        (VAR & VAR_PLAIN_LOAD) ? 0 : 2);
-                }
-            }
-        else
             {
             uint32_t v = tid;
             // four independent 16-byte loads in flight per lane
             for (; v + 3 * NT < nvec; v += 4 * NT)
                 {
-                u32x4 a = stream_load<VAR>((const u32x4*)gsrc + v);
-                u32x4 b = stream_load<VAR>((const u32x4*)gsrc + v + NT);
-                u32x4 c = stream_load<VAR>((const u32x4*)gsrc + v + 2 * NT);
-                u32x4 d = stream_load<VAR>((const u32x4*)gsrc + v + 3 * NT);
-                *(u32x4*)(lds + lds_skew<VAR>(v << 4)) = a;
-                *(u32x4*)(lds + lds_skew<VAR>((v + NT) << 4)) = b;
-                *(u32x4*)(lds + lds_skew<VAR>((v + 2 * NT) << 4)) = c;
-                *(u32x4*)(lds + lds_skew<VAR>((v + 3 * NT) << 4)) = d;
+                u32x4 a = stream_load((const u32x4*)gsrc + v);
+                u32x4 b = stream_load((const u32x4*)gsrc + v + NT);
+                u32x4 c = stream_load((const u32x4*)gsrc + v + 2 * NT);
+                u32x4 d = stream_load((const u32x4*)gsrc + v + 3 * NT);
+                *(u32x4*)(lds + lds_skew(v << 4)) = a;
+                *(u32x4*)(lds + lds_skew((v + NT) << 4)) = b;
+                *(u32x4*)(lds + lds_skew((v + 2 * NT) << 4)) = c;
+                *(u32x4*)(lds + lds_skew((v + 3 * NT) << 4)) = d;
                 }
             for (; v < nvec; v += NT)
-                *(u32x4*)(lds + lds_skew<VAR>(v << 4)) = stream_load<VAR>((const u32x4*)gsrc + v);
+                *(u32x4*)(lds + lds_skew(v << 4)) = stream_load((const u32x4*)gsrc + v);
             }
         for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += NT)
-            lds[lds_skew<VAR>(b)] = gsrc[b];
+            lds[lds_skew(b)] = gsrc[b];
         }
     else
         {
@@ -324,13 +292,13 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
                 u32x4 b = *((const u32x4*)g.src + o1);
                 u32x4 c = *((const u32x4*)g.src + o2);
                 u32x4 d = *((const u32x4*)g.src + o3);
-                *(u32x4*)(lds + lds_skew<VAR>(i << 4)) = a;
-                *(u32x4*)(lds + lds_skew<VAR>((i + NT) << 4)) = b;
-                *(u32x4*)(lds + lds_skew<VAR>((i + 2 * NT) << 4)) = c;
-                *(u32x4*)(lds + lds_skew<VAR>((i + 3 * NT) << 4)) = d;
+                *(u32x4*)(lds + lds_skew(i << 4)) = a;
+                *(u32x4*)(lds + lds_skew((i + NT) << 4)) = b;
+                *(u32x4*)(lds + lds_skew((i + 2 * NT) << 4)) = c;
+                *(u32x4*)(lds + lds_skew((i + 3 * NT) << 4)) = d;
                 }
             for (; i < rows; i += NT)
-                *(u32x4*)(lds + lds_skew<VAR>(i << 4)) = *((const u32x4*)g.src + ord[i]);
+                *(u32x4*)(lds + lds_skew(i << 4)) = *((const u32x4*)g.src + ord[i]);
             }
         else if (rowbytes == 32)
             {
@@ -340,16 +308,16 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
                 const uint64_t o0 = ord[i], o1 = ord[i + NT];
                 u32x4 a0 = *((const u32x4*)g.src + 2 * o0), a1 = *((const u32x4*)g.src + 2 * o0 + 1);
                 u32x4 b0 = *((const u32x4*)g.src + 2 * o1), b1 = *((const u32x4*)g.src + 2 * o1 + 1);
-                *(u32x4*)(lds + lds_skew<VAR>((2 * i) << 4)) = a0;
-                *(u32x4*)(lds + lds_skew<VAR>((2 * i + 1) << 4)) = a1;
-                *(u32x4*)(lds + lds_skew<VAR>((2 * (i + NT)) << 4)) = b0;
-                *(u32x4*)(lds + lds_skew<VAR>((2 * (i + NT) + 1) << 4)) = b1;
+                *(u32x4*)(lds + lds_skew((2 * i) << 4)) = a0;
+                *(u32x4*)(lds + lds_skew((2 * i + 1) << 4)) = a1;
+                *(u32x4*)(lds + lds_skew((2 * (i + NT)) << 4)) = b0;
+                *(u32x4*)(lds + lds_skew((2 * (i + NT) + 1) << 4)) = b1;
                 }
             for (; i < rows; i += NT)
                 {
                 const uint64_t o0 = ord[i];
-                *(u32x4*)(lds + lds_skew<VAR>((2 * i) << 4)) = *((const u32x4*)g.src + 2 * o0);
-                *(u32x4*)(lds + lds_skew<VAR>((2 * i + 1) << 4)) = *((const u32x4*)g.src + 2 * o0 + 1);
+                *(u32x4*)(lds + lds_skew((2 * i) << 4)) = *((const u32x4*)g.src + 2 * o0);
+                *(u32x4*)(lds + lds_skew((2 * i + 1) << 4)) = *((const u32x4*)g.src + 2 * o0 + 1);
                 }
             }
         else if ((rowbytes & 3) == 0)
@@ -359,7 +327,7 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
             for (uint32_t i = tid; i < nw; i += NT)
                 {
                 uint32_t r = i / wpr, c = i - r * wpr;
-                *(uint32_t*)(lds + lds_skew<VAR>(i << 2)) = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
+                *(uint32_t*)(lds + lds_skew(i << 2)) = *((const uint32_t*)g.src + (uint64_t)ord[r] * wpr + c);
                 }
             }
         else
@@ -368,7 +336,7 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
             for (uint32_t i = tid; i < nb; i += NT)
                 {
                 uint32_t r = i / rowbytes, c = i - r * rowbytes;
-                lds[lds_skew<VAR>(i)] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
+                lds[lds_skew(i)] = *((const char*)g.src + (uint64_t)ord[r] * rowbytes + c);
                 }
             }
         }
@@ -379,7 +347,7 @@ __device__ __forceinline__ void stage_rows(const PackGroup& g, char* lds, uint32
 // workgroups round-robin, so the workgroups resident at any moment stream one contiguous
 // window of every array (DRAM-page friendly).  Per tile and source group: stage -> barrier
 // -> emit every chunk fed by that source -> barrier.
-template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
+template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_kernel(const PackArgs args)
     {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t tid = threadIdx.x;
@@ -395,10 +363,10 @@ template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack
             {
             const uint32_t g0 = args.batch_start[b], g1 = args.batch_start[b + 1];
             for (uint32_t gi = g0; gi < g1; gi++)
-                stage_rows<PACK_THREADS, VAR>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
+                stage_rows<PACK_THREADS>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
             __syncthreads();
             for (uint32_t gi = g0; gi < g1; gi++)
-                emit_group<PACK_THREADS, MODE, VAR>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
+                emit_group<PACK_THREADS, MODE>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
             __syncthreads();
             }
         }
@@ -458,12 +426,12 @@ template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_pr
                 {
                 const uint32_t v = tid + k * PACK_THREADS;
                 if (v < nvec)
-                    *(u32x4*)(l + lds_skew<0>(v << 4)) = r[gi * PF_VECS + k];
+                    *(u32x4*)(l + lds_skew(v << 4)) = r[gi * PF_VECS + k];
                 }
             // ragged end of the last tile
             const char* gsrc = (const char*)g.src + row0 * g.rowbytes;
             for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
-                l[lds_skew<0>(b)] = gsrc[b];
+                l[lds_skew(b)] = gsrc[b];
             }
     };
 
@@ -479,67 +447,8 @@ template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_pr
         if (tile + gridDim.x < args.n_tiles)
             issue(tile + gridDim.x);
         for (uint32_t gi = 0; gi < args.n_groups; gi++)
-            emit_group<PACK_THREADS, MODE, 0>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
+            emit_group<PACK_THREADS, MODE>(args.g[gi], lds + args.g[gi].lds_off, rows, row0, tid);
         __syncthreads();
-        }
-    }
-
-// Wave-streaming kernel: every 64-lane wavefront owns a private PACK_WAVE_LDS-byte LDS
-// window and steps through `wave_rows`-row pieces dealt round-robin over all waves of the
-// grid; no workgroup barrier exists (LDS operations of one wave execute in program
-// order), so waves never wait for each other.  Dense same-type fields bypass LDS.
-template<int MODE, int VAR> __global__ __launch_bounds__(PACK_THREADS) void pack_waves_kernel(const PackArgs args)
-    {
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    char* lds = lds_all + wave * PACK_WAVE_LDS_SKEWED;
-    const uint64_t gw = (uint64_t)blockIdx.x * (PACK_THREADS / 64) + wave;
-    const uint64_t nw = (uint64_t)gridDim.x * (PACK_THREADS / 64);
-
-    for (uint32_t gi = 0; gi < args.n_groups; gi++)
-        {
-        const PackGroup& g = args.g[gi];
-        const uint32_t W = g.wave_rows;
-        const uint64_t n_steps = (args.N + W - 1) / W;
-        for (uint64_t step = gw; step < n_steps; step += nw)
-            {
-            const uint64_t row0 = step * W;
-            const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)W) ? args.N - row0 : W);
-            if (g.direct)
-                {
-                // dense copy: chunk bytes == source bytes
-                const char* gsrc = (const char*)g.src + row0 * g.rowbytes;
-                char* gdst = (char*)g.out[0].dst + row0 * g.rowbytes;
-                const uint32_t nbytes = rows * g.rowbytes;
-                const uint32_t nvec = nbytes >> 4;
-                uint32_t v = lane;
-                for (; v + 3 * 64 < nvec; v += 4 * 64)
-                    {
-                    u32x4 a = stream_load<VAR>((const u32x4*)gsrc + v);
-                    u32x4 b = stream_load<VAR>((const u32x4*)gsrc + v + 64);
-                    u32x4 c = stream_load<VAR>((const u32x4*)gsrc + v + 128);
-                    u32x4 d = stream_load<VAR>((const u32x4*)gsrc + v + 192);
-                    stream_store<VAR>(a, (u32x4*)gdst + v);
-                    stream_store<VAR>(b, (u32x4*)gdst + v + 64);
-                    stream_store<VAR>(c, (u32x4*)gdst + v + 128);
-                    stream_store<VAR>(d, (u32x4*)gdst + v + 192);
-                    }
-                for (; v < nvec; v += 64)
-                    stream_store<VAR>(stream_load<VAR>((const u32x4*)gsrc + v), (u32x4*)gdst + v);
-                for (uint32_t b = (nvec << 4) + lane; b < nbytes; b += 64)
-                    gdst[b] = gsrc[b];
-                continue;
-                }
-            stage_rows<64, VAR & ~VAR_GLDS>(g, lds, rows, row0, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            emit_group<64, MODE, VAR>(g, lds, rows, row0, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
         }
     }
 
@@ -1193,61 +1102,34 @@ static int num_cus()
     return g_num_cus;
     }
 
-template<int MODE, int VAR>
-static void launch_one(bool waves, unsigned blocks, size_t lds_bytes, hipStream_t stream, const PackArgs& args,
-                       hipEvent_t ev_start, hipEvent_t ev_stop)
+// the LDS-tiled kernels: plain or software-pipelined, one instantiation per conversion class
+static void launch_tiles(bool prefetch, int mode, unsigned blocks, size_t lds_bytes, hipStream_t stream,
+                         const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
     {
     // hipExtLaunchKernelGGL stamps the events with the dispatch's own begin / end times, so a
     // profiled launch measures the kernel and nothing else (what rocprofv3 reports)
-    if (waves)
-        hipExtLaunchKernelGGL((pack_waves_kernel<MODE, VAR & ~VAR_GLDS>), dim3(blocks), dim3(PACK_THREADS),
-                              (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
-    else
-        hipExtLaunchKernelGGL((pack_tiles_kernel<MODE, VAR>), dim3(blocks), dim3(PACK_THREADS), (uint32_t)lds_bytes,
-                              stream, ev_start, ev_stop, 0, args);
-    }
-
-template<int MODE>
-static void launch_mode(bool waves, int var, unsigned blocks, size_t lds_bytes, hipStream_t stream,
-                        const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
-    {
-    switch (var & 15)
-        {
-        case 8: launch_one<MODE, 8>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 12: launch_one<MODE, 12>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 0: launch_one<MODE, 0>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 1: launch_one<MODE, 1>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 2: launch_one<MODE, 2>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 3: launch_one<MODE, 3>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 4: launch_one<MODE, 4>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 5: launch_one<MODE, 5>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        case 6: launch_one<MODE, 6>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        default: launch_one<MODE, 7>(waves, blocks, lds_bytes, stream, args, ev_start, ev_stop); break;
-        }
-    }
-
-static void launch_variant(bool waves, bool prefetch, int mode, int var, unsigned blocks, size_t lds_bytes,
-                           hipStream_t stream, const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
-    {
-    if (prefetch && !waves)
+#define TILES_LAUNCH(KERNEL, MODE)                                                                              \
+    hipExtLaunchKernelGGL((KERNEL<MODE>), dim3(blocks), dim3(PACK_THREADS), (uint32_t)lds_bytes, stream, ev_start, \
+                          ev_stop, 0, args)
+    if (prefetch)
         {
         if (mode == PACK_MODE_W32)
-            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_W32>), dim3(blocks), dim3(PACK_THREADS),
-                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
+            TILES_LAUNCH(pack_tiles_prefetch_kernel, PACK_MODE_W32);
         else if (mode == PACK_MODE_F64_F32)
-            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_F64_F32>), dim3(blocks), dim3(PACK_THREADS),
-                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
+            TILES_LAUNCH(pack_tiles_prefetch_kernel, PACK_MODE_F64_F32);
         else
-            hipExtLaunchKernelGGL((pack_tiles_prefetch_kernel<PACK_MODE_GENERIC>), dim3(blocks), dim3(PACK_THREADS),
-                                  (uint32_t)lds_bytes, stream, ev_start, ev_stop, 0, args);
-        return;
+            TILES_LAUNCH(pack_tiles_prefetch_kernel, PACK_MODE_GENERIC);
         }
-    if (mode == PACK_MODE_W32)
-        launch_mode<PACK_MODE_W32>(waves, var, blocks, lds_bytes, stream, args, ev_start, ev_stop);
-    else if (mode == PACK_MODE_F64_F32)
-        launch_mode<PACK_MODE_F64_F32>(waves, var, blocks, lds_bytes, stream, args, ev_start, ev_stop);
     else
-        launch_mode<PACK_MODE_GENERIC>(waves, (var & VAR_GLDS), blocks, lds_bytes, stream, args, ev_start, ev_stop);
+        {
+        if (mode == PACK_MODE_W32)
+            TILES_LAUNCH(pack_tiles_kernel, PACK_MODE_W32);
+        else if (mode == PACK_MODE_F64_F32)
+            TILES_LAUNCH(pack_tiles_kernel, PACK_MODE_F64_F32);
+        else
+            TILES_LAUNCH(pack_tiles_kernel, PACK_MODE_GENERIC);
+        }
+#undef TILES_LAUNCH
     }
 
 // ---- row-per-lane launches
@@ -1378,12 +1260,11 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
     enum
         {
         K_ROWS,
-        K_TILES,
-        K_WAVES
+        K_TILES
         } kernel
         = K_ROWS;
-    if (const char* e = getenv("PGSD_PACK_KERNEL"))
-        kernel = strcmp(e, "waves") == 0 ? K_WAVES : (strcmp(e, "tiles") == 0 ? K_TILES : K_ROWS);
+    if (const char* e = getenv("PGSD_PACK_KERNEL")) // "tiles": the LDS-tiled kernel for everything (A/B, tests)
+        kernel = strcmp(e, "tiles") == 0 ? K_TILES : K_ROWS;
 
     // 1. the row-per-lane kernel takes every job it can: one launch per class of source-row width (a
     //    compile-time parameter), dense same-type arrays ride along in any launch; up to ROWS_MAX_GROUPS
@@ -1564,94 +1445,62 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         if (!any)
             break;
-        bool use_waves = kernel == K_WAVES;
         uint64_t per_cu = 4;
-        int var = 0;
         uint32_t tile_cap = 1024;
         if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
             per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
-        if (const char* e = getenv("PGSD_PACK_VARIANT"))
-            var = atoi(e) & 15;
         if (const char* e = getenv("PGSD_PACK_TILE"))
             tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
-        if (max_rowbytes * 16 > PACK_WAVE_LDS)
-            use_waves = false; // a source row too wide for a wave's LDS window
-        if (use_waves)
+        size_t lds_budget = PACK_LDS_BYTES;
+        if (const char* e = getenv("PGSD_PACK_LDS_KB"))
+            lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
+        // tile: as many rows as the widest source row allows (power of two in [16, tile_cap]);
+        // consecutive source arrays then share a batch while their tiles fit the budget
+        uint32_t tile = 16;
+        while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * max_rowbytes <= lds_budget)
+            tile <<= 1;
+        args.tile_rows = tile;
+        args.n_tiles = (N + tile - 1) / tile;
+        size_t lds_bytes = 0, used = 0;
+        args.n_batches = 0;
+        args.batch_start[0] = 0;
+        for (uint32_t k = 0; k < args.n_groups; k++)
             {
-            for (uint32_t k = 0; k < args.n_groups; k++)
+            size_t lin = (size_t)tile * args.g[k].rowbytes;
+            size_t need = (lin + ((lin >> 7) << 4) + 31) & ~(size_t)15; // see lds_skew
+            if (used != 0 && used + need > lds_budget)
                 {
-                PackGroup& g = args.g[k];
-                uint32_t w = (PACK_WAVE_LDS / g.rowbytes) & ~15u;
-                g.wave_rows = w > 1024 ? 1024 : w;
-                const PackOut& o = g.out[0];
-                g.direct = (g.n_out == 1 && g.order == nullptr && o.M == g.stride && o.col0 == 0
-                            && o.kind == PACK_BITS && o.dsz == g.ssz)
-                               ? 1u
-                               : 0u;
+                args.batch_start[++args.n_batches] = (uint8_t)k;
+                used = 0;
                 }
-            uint64_t blocks = (uint64_t)num_cus() * per_cu;
-            uint64_t max_blocks = (N + 255) / 256;
-            if (blocks > max_blocks)
-                blocks = max_blocks;
-            const size_t lds_bytes = (size_t)(PACK_THREADS / 64) * PACK_WAVE_LDS_SKEWED;
-            launches.push_back(
-                [=](hipEvent_t e0, hipEvent_t e1)
-                { launch_variant(true, false, mode, var, (unsigned)blocks, lds_bytes, stream, args, e0, e1); });
+            args.g[k].lds_off = (uint32_t)used;
+            used += need;
+            lds_bytes = std::max(lds_bytes, used);
             }
-        else
-            {
-            size_t lds_budget = PACK_LDS_BYTES;
-            if (const char* e = getenv("PGSD_PACK_LDS_KB"))
-                lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
-            // tile: as many rows as the widest source row allows (power of two in [16, tile_cap]);
-            // consecutive source arrays then share a batch while their tiles fit the budget
-            uint32_t tile = 16;
-            while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * max_rowbytes <= lds_budget)
-                tile <<= 1;
-            args.tile_rows = tile;
-            args.n_tiles = (N + tile - 1) / tile;
-            size_t lds_bytes = 0, used = 0;
-            args.n_batches = 0;
-            args.batch_start[0] = 0;
-            for (uint32_t k = 0; k < args.n_groups; k++)
-                {
-                size_t lin = (size_t)tile * args.g[k].rowbytes;
-                const bool skewed = !(var & (VAR_GLDS | VAR_LINEAR_LDS));
-                size_t need = ((skewed ? lin + ((lin >> 7) << 4) : lin) + 31) & ~(size_t)15; // see lds_skew
-                if (used != 0 && used + need > lds_budget)
-                    {
-                    args.batch_start[++args.n_batches] = (uint8_t)k;
-                    used = 0;
-                    }
-                args.g[k].lds_off = (uint32_t)used;
-                used += need;
-                lds_bytes = std::max(lds_bytes, used);
-                }
-            args.batch_start[++args.n_batches] = (uint8_t)args.n_groups;
-            // never ask for more workgroups per CU than the 160 KiB of LDS admit: the surplus
-            // would queue behind the resident ones and run as a ragged second wave
-            uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
-            if (resident < 1)
-                resident = 1;
-            uint64_t blocks = args.n_tiles;
-            uint64_t cap = (uint64_t)num_cus() * std::min<uint64_t>(per_cu, resident);
-            if (blocks > cap)
-                blocks = cap;
-            // the software-pipelined kernel takes launches it has registers for: one batch, linear
-            // sources, tiles of at most PF_VECS x 256 vectors, default variant
-            bool prefetch = args.n_batches == 1 && args.n_groups <= PF_GROUPS && var == 0;
-            for (uint32_t k = 0; k < args.n_groups; k++)
-                prefetch = prefetch && args.g[k].order == nullptr
-                           && (size_t)tile * args.g[k].rowbytes <= (size_t)PF_VECS * PACK_THREADS * 16;
-            int want = -1; // -1: by size
-            if (const char* e = getenv("PGSD_PACK_PREFETCH"))
-                want = atoi(e);
-            if (want == 0 || (want < 0 && args.n_tiles > 2 * blocks))
-                prefetch = false;
-            launches.push_back(
-                [=](hipEvent_t e0, hipEvent_t e1)
-                { launch_variant(false, prefetch, mode, var, (unsigned)blocks, lds_bytes, stream, args, e0, e1); });
-            }
+        args.batch_start[++args.n_batches] = (uint8_t)args.n_groups;
+        // never ask for more workgroups per CU than the 160 KiB of LDS admit: the surplus
+        // would queue behind the resident ones and run as a ragged second wave
+        uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
+        if (resident < 1)
+            resident = 1;
+        uint64_t blocks = args.n_tiles;
+        uint64_t cap = (uint64_t)num_cus() * std::min<uint64_t>(per_cu, resident);
+        if (blocks > cap)
+            blocks = cap;
+        // the software-pipelined kernel takes launches it has registers for: one batch, linear
+        // sources, tiles of at most PF_VECS x 256 vectors
+        bool prefetch = args.n_batches == 1 && args.n_groups <= PF_GROUPS;
+        for (uint32_t k = 0; k < args.n_groups; k++)
+            prefetch = prefetch && args.g[k].order == nullptr
+                       && (size_t)tile * args.g[k].rowbytes <= (size_t)PF_VECS * PACK_THREADS * 16;
+        int want = -1; // -1: by size
+        if (const char* e = getenv("PGSD_PACK_PREFETCH"))
+            want = atoi(e);
+        if (want == 0 || (want < 0 && args.n_tiles > 2 * blocks))
+            prefetch = false;
+        launches.push_back(
+            [=](hipEvent_t e0, hipEvent_t e1)
+            { launch_tiles(prefetch, mode, (unsigned)blocks, lds_bytes, stream, args, e0, e1); });
         while (next < n_jobs && done[next])
             next++;
         }

@@ -17,8 +17,6 @@ enum
     PACK_MAX_GROUPS = 8,       // distinct source arrays per launch
     PACK_MAX_OUT = 6,          // chunks fed from one source array
     PACK_LDS_BYTES = 49152,    // LDS budget per workgroup of the workgroup-tiled kernel (3 workgroups per CU)
-    PACK_WAVE_LDS = 4096,      // private LDS window of one wavefront in the wave-streaming kernel
-    PACK_WAVE_LDS_SKEWED = 4096 + 4096 / 8 + 16, // the same window with the bank skew applied
     PACK_MAX_ROWBYTES = 2048,  // wider source rows take the generic kernel
     PACK_MAX_M = 1024
     };
@@ -33,7 +31,7 @@ enum
     PACK_S2F = 4   // signed integer (<= 32 bit) -> f32 / f64
     };
 
-// compile-time specialisations of the wave-streaming kernel
+// compile-time specialisations of the LDS-tiled kernels
 enum
     {
     PACK_MODE_GENERIC = 0, // any element sizes / conversions, decided at run time per output
@@ -60,8 +58,7 @@ struct PackGroup
     uint32_t ssz;          // bytes per source element
     uint32_t stride;       // elements per source row
     uint32_t n_out;
-    uint32_t wave_rows;    // rows per step of one wave (multiple of 16, wave_rows*rowbytes <= PACK_WAVE_LDS)
-    uint32_t direct;       // 1: single dense same-type output, chunk bytes == source bytes
+    uint32_t pad0[2];
     uint32_t lds_off;      // byte offset of this group's tile inside the workgroup's LDS (tiles kernel)
     uint32_t pad;
     PackOut out[PACK_MAX_OUT];

@@ -7,6 +7,14 @@ import gpu_common as G
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["rows", "tiles"], autouse=True)
+def pack_kernel_family(request, monkeypatch):
+    """Every parity test runs through both kernel families: the row-per-lane kernel (the default for 4- and
+    8-byte elements) and the LDS-tiled kernel, which takes everything when PGSD_PACK_KERNEL=tiles."""
+    monkeypatch.setenv("PGSD_PACK_KERNEL", request.param)
+    return request.param
+
 torch = pytest.importorskip("torch")
 
 INTS = ["uint8", "uint16", "uint32", "uint64", "int8", "int16", "int32", "int64"]

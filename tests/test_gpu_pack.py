@@ -12,6 +12,14 @@ import gpu_common as G
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["rows", "tiles"], autouse=True)
+def pack_kernel_family(request, monkeypatch):
+    """Every parity test runs through both kernel families: the row-per-lane kernel (the default for 4- and
+    8-byte elements) and the LDS-tiled kernel, which takes everything when PGSD_PACK_KERNEL=tiles."""
+    monkeypatch.setenv("PGSD_PACK_KERNEL", request.param)
+    return request.param
+
 torch = pytest.importorskip("torch")
 
 SIZES = [1, 3, 63, 64, 65, 1000, 1023, 1024, 1025, 4099, 100003]

@@ -3,8 +3,8 @@
 
 Rotates enough independent buffer sets that no byte is re-read from the 256 MiB Infinity Cache
 between launches, times with HIP events on the launch stream, and prints algorithmic and
-moved GB/s per workload.  Kernel variants are selected with the PGSD_PACK_* environment
-variables read by the launcher (PGSD_PACK_KERNEL=tiles|waves, PGSD_PACK_BLOCKS_PER_CU=n).
+moved GB/s per workload.  Kernels and launch shapes are selected with the PGSD_PACK_* environment
+variables read by the launcher (PGSD_PACK_KERNEL=rows|tiles, PGSD_PACK_ROWS_CFG=256x2, ...).
 """
 import argparse
 import ctypes
@@ -95,7 +95,7 @@ def make_jobs(workload, N, gen):
 
 
 KERNEL_ONLY = False
-AB_KEYS = ("PGSD_PACK_VARIANT", "PGSD_PACK_KERNEL", "PGSD_PACK_ROWS_CFG", "PGSD_PACK_TILE", "PGSD_PACK_BLOCKS_PER_CU")
+AB_KEYS = ("PGSD_PACK_KERNEL", "PGSD_PACK_ROWS_CFG", "PGSD_PACK_TILE", "PGSD_PACK_BLOCKS_PER_CU", "PGSD_PACK_PREFETCH")
 
 
 def to_c(jobs):
@@ -137,16 +137,13 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
             torch.cuda.synchronize()
             time.sleep(sleep_ms * 1e-3)   # let the GPU idle between launches, like a snapshot every few ms
         if variants:
-            # interleaved A/B in one process: "3" = PGSD_PACK_VARIANT=3, "K=V+K2=V2" = those variables
+            # interleaved A/B in one process: "K=V+K2=V2" sets those PGSD_PACK_* variables for this launch
             v = variants[i % len(variants)]
             for k in AB_KEYS:
                 os.environ.pop(k, None)
-            if "=" in v:
-                for kv in v.split("+"):
-                    k, _, val = kv.partition("=")
-                    os.environ[k] = val
-            else:
-                os.environ["PGSD_PACK_VARIANT"] = v
+            for kv in v.split("+"):
+                k, _, val = kv.partition("=")
+                os.environ[k] = val
         evs[i][0].record()
         if KERNEL_ONLY:
             # the dispatches' own begin / end stamps (what rocprofv3 reports): no launch latency in the figure
@@ -177,8 +174,8 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sleep-ms", type=float, default=0.0)
-    ap.add_argument("--variants", default="", help="comma list of variants to interleave launch by launch: a "
-                    "PGSD_PACK_VARIANT value, or KEY=VALUE[+KEY=VALUE] settings of the PGSD_PACK_* variables")
+    ap.add_argument("--variants", default="", help="comma list of variants to interleave launch by launch: "
+                    "KEY=VALUE[+KEY=VALUE] settings of the PGSD_PACK_* variables")
     ap.add_argument("--kernel-only", action="store_true",
                     help="time with the dispatches' own stamps (pgsd_pack_fields_timed) instead of stream events "
                          "around the call")
