@@ -45,6 +45,12 @@
  *   end_frame | flush | close | dump
  *   maxbuf <bytes> | idxbuf <entries>
  *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
+ *   read <frame> <name> <N> <M> <row_offset> <all 0|1> <bufN> <bufM> <size>
+ *         pgsd_find_chunk + pgsd_read_chunk (pgsd.h:581-610) on every rank (the reference's read is
+ *         collective: rank 0's entry is broadcast, pgsd.c:2491-2494); all=0 reads the whole chunk, all=1
+ *         rows [row_offset, row_offset+N) x M.  <bufN> x <bufM> elements of <size> bytes is what the
+ *         buffer must hold (ranks other than 0 cannot look at the entry in the reference).  Rank 0 prints
+ *         the return code and an FNV-1a hash of the bytes it read.
  *   names <prefix>                 (prints matching chunk names on rank 0)
  */
 #include "pgsd.h"
@@ -365,6 +371,36 @@ int main(int argc, char** argv)
                 else
                     printf("find line=%d frame=%s name=%s NOTFOUND\n", lineno, tok[1], tok[2]);
                 }
+            }
+        else if (strcmp(cmd, "read") == 0 && nt == 10)
+            {
+            uint64_t frame = strtoull(tok[1], NULL, 10);
+            uint64_t N = strtoull(tok[3], NULL, 10);
+            uint32_t M = (uint32_t)strtoul(tok[4], NULL, 10);
+            uint32_t off = (uint32_t)strtoul(tok[5], NULL, 10);
+            int all = atoi(tok[6]);
+            size_t bytes = (size_t)strtoull(tok[7], NULL, 10) * strtoull(tok[8], NULL, 10) * strtoull(tok[9], NULL, 10);
+            unsigned char* buf = (unsigned char*)calloc(bytes ? bytes : 1, 1);
+            const struct pgsd_index_entry* e = pgsd_find_chunk(&handle, frame, tok[2]);
+            int rrc = pgsd_read_chunk(&handle, buf, e, N, M, off, all != 0);
+            if (g_rank == 0)
+                {
+                uint64_t h = 0xcbf29ce484222325ull;
+                size_t got = 0;
+                if (rrc == 0 && e)
+                    got = all ? (size_t)(N * M) * pgsd_sizeof_type((enum pgsd_type)e->type)
+                              : (size_t)(e->N * e->M) * pgsd_sizeof_type((enum pgsd_type)e->type);
+                if (got > bytes)
+                    got = bytes;
+                for (size_t i = 0; i < got; i++)
+                    {
+                    h ^= buf[i];
+                    h *= 0x100000001b3ull;
+                    }
+                printf("read line=%d frame=%s name=%s N=%s M=%s offset=%s all=%d rc=%d bytes=%zu fnv=%016" PRIx64 "\n",
+                       lineno, tok[1], tok[2], tok[3], tok[4], tok[5], all, rrc, got, h);
+                }
+            free(buf);
             }
         else if (strcmp(cmd, "names") == 0 && nt <= 2)
             {

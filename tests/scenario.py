@@ -253,6 +253,22 @@ def run_oracle(script, out_path, P):
                            % (lineno, tok[1], tok[2], e.N, e.M, e.type, e.location, e.id))
             else:
                 log.append("find line=%d frame=%s name=%s NOTFOUND" % (lineno, tok[1], tok[2]))
+        elif cmd == "read":
+            frame, name = int(tok[1]), tok[2]
+            N, M, off, all_ = int(tok[3]), int(tok[4]), int(tok[5]), int(tok[6])
+            nbytes = int(tok[7]) * int(tok[8]) * int(tok[9])
+            buf = np.zeros(max(nbytes, 1), dtype=np.uint8)
+            e = lib.oracle_find_chunk(h, frame, name.encode())
+            rrc = lib.oracle_read_chunk(h, buf.ctypes.data, e, N, M, off, bool(all_)) if e else -2
+            got = 0
+            if rrc == 0 and e:
+                esz = np.dtype(NP_TYPES[e.contents.type]).itemsize
+                got = min((N * M if all_ else e.contents.N * e.contents.M) * esz, nbytes)
+            hv = 0xcbf29ce484222325
+            for byte in buf[:got].tolist():
+                hv = ((hv ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+            log.append("read line=%d frame=%s name=%s N=%s M=%s offset=%s all=%d rc=%d bytes=%d fnv=%016x"
+                       % (lineno, tok[1], name, tok[3], tok[4], tok[5], all_, rrc, got, hv))
         elif cmd == "names":
             prefix = tok[1] if len(tok) > 1 else ""
             found = []

@@ -17,6 +17,7 @@ import scenario as S
 REF_DRIVER = os.path.join(S.ROOT, "oracle", "_ref", "ref_driver")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 TYPES = ["u8", "u16", "u32", "u64", "i8", "i16", "i32", "i64", "f32", "f64"]
+ESZ = {"u8": 1, "i8": 1, "u16": 2, "i16": 2, "u32": 4, "i32": 4, "f32": 4, "u64": 8, "i64": 8, "f64": 8}
 NAMES = ["configuration/step", "particles/N", "particles/position", "particles/velocity", "particles/typeid",
          "particles/image", "log/e", "a", "b/c", "x" * 70, "particles/a_rather_long_auxiliary_chunk_name_number_1",
          "q/0", "q/1", "q/2"]
@@ -33,14 +34,19 @@ def make_script(seed, P):
         lines.append("maxbuf %d" % maxbuf)
     names = rng.sample(NAMES, rng.randint(3, len(NAMES)))
     n_frames = rng.randint(2, 14)
+    cur, last_nonempty = 0, -1      # the file's frame counter: a re-open continues behind the last frame that has entries
     for frame in range(n_frames):
         lines.append("seed %d" % rng.randint(0, 10 ** 6))
         used = set()
         hole = False
+        shapes = {}             # name -> (rows of the whole chunk, M, element size) for the read-backs below
+        dups = set()
         for _ in range(rng.randint(0, 9)):
             name = rng.choice(names)
             if name in used and rng.random() < 0.9:
                 continue
+            if name in used:
+                dups.add(name)      # written twice in one frame: which entry a read finds is the sort's business
             used.add(name)
             t = rng.choice(TYPES)
             M = rng.randint(1, 4)
@@ -52,6 +58,7 @@ def make_script(seed, P):
                 n = rng.randint(1, 30)
                 gs = rng.choice([n * M, n * M, 0, 1, 10 ** 9])
                 lines.append("samechunk %s %s %d %d %d %d 0 %d 1" % (name, t, n, M, n, M, gs))
+                shapes[name] = (n, M, ESZ[t])
                 hole = True
             elif shape < 0.22:
                 # a proper partition with a global_size that is not the sum (dead argument, pgsd.c:2147-2151)
@@ -60,12 +67,14 @@ def make_script(seed, P):
                 else:
                     dist = "even:%d" % rng.randint(0, 120)
                 lines.append("chunkgs %s %s %d 1 %s %d" % (name, t, M, dist, rng.choice([0, 1, 7, 10 ** 12])))
+                shapes[name] = (sum(S.dist_counts(dist, P)), M, ESZ[t])
             elif shape < 0.60:
                 if rng.random() < 0.3:
                     dist = "list:" + ",".join(str(rng.choice([0, 0, 1, 3, 17, 40])) for _ in range(P))
                 else:
                     dist = "even:%d" % rng.randint(0, 120)
                 lines.append("chunk %s %s %d 1 %s" % (name, t, M, dist))
+                shapes[name] = (sum(S.dist_counts(dist, P)), M, ESZ[t])
             else:
                 lo = 0 if P == 1 else 1    # zero-size replicated chunks dead-lock the reference at P > 1
                 n = rng.randint(lo, 30)
@@ -78,6 +87,7 @@ def make_script(seed, P):
                     esz = {"8": 1, "16": 2, "32": 4, "64": 8}[t[1:]]
                     n = max(lo, min(n, (maxbuf - 1) // (M * esz)))
                 lines.append("chunk %s %s %d 0 same:%d" % (name, t, M, n))
+                shapes[name] = (n, M, ESZ[t])
             if rng.random() < 0.05:
                 lines.append("flush")
         if hole and P > 1:
@@ -86,6 +96,22 @@ def make_script(seed, P):
             # the reference needs on re-open (see the seed-114 note above)
             lines.append("chunk fuzz/tail u32 1 1 even:%d" % (P + rng.randint(0, 5)))
         lines.append("end_frame")
+        if used:
+            last_nonempty = cur
+        this_frame, cur = cur, cur + 1
+        # read some of the frame back: whole chunks and row slabs (pgsd_find_chunk + pgsd_read_chunk, collective
+        # in the reference); a chunk without rows answers PGSD_ERROR_FILE_CORRUPT in all three implementations
+        for name in dups:
+            shapes.pop(name, None)
+        if shapes and rng.random() < 0.35:
+            for name in rng.sample(sorted(shapes), min(len(shapes), rng.randint(1, 2))):
+                rows, M, esz = shapes[name]
+                if rng.random() < 0.5 or rows == 0:
+                    lines.append("read %d %s 0 %d 0 0 %d %d %d" % (this_frame, name, M, max(rows, 1), M, esz))
+                else:
+                    n = rng.randint(1, rows)
+                    off = rng.randint(0, rows - n)
+                    lines.append("read %d %s %d %d %d 1 %d %d %d" % (this_frame, name, n, M, off, n, M, esz))
         r = rng.random()
         if r < 0.25:
             lines.append("dump")
@@ -93,6 +119,7 @@ def make_script(seed, P):
             lines.append("find %d %s" % (rng.randint(0, frame), rng.choice(names)))
         elif r < 0.42:
             lines += ["close", "open %s" % rng.choice(["rw", "append"]), "dump"]
+            cur = last_nonempty + 1
             maxbuf = 64 * 1024 * 1024          # a fresh handle starts from the default
             if rng.random() < 0.5:
                 maxbuf = rng.choice([64, 4096])
