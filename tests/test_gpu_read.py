@@ -1,11 +1,13 @@
 """Read path on the GPU (BASELINE config 5): file -> pinned slabs -> HBM -> HIP unpack, against
 the pure-Python reader (pgsd.pypgsd) on the same file. Bit-exact."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 
 import gpu_common as G
+import scenario as S
 
 pytestmark = pytest.mark.gpu
 
@@ -311,3 +313,40 @@ def test_many_reading_handles_share_one_reader_engine(tmp_path):
     with fl.open(paths[0], 'r') as f:
         got = f.read_chunk_device(0, 'particles/typeid')
         assert got.shape[0] == N
+
+
+def _fnv1a(data):
+    h = 0xcbf29ce484222325
+    for b in data:
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_device_reads_reproduce_the_references_own_read_hashes(P):
+    """tests/golden/files/readback.p<P>.{gsd,log} were written AND read by the compiled reference
+    (pgsd_find_chunk + pgsd_read_chunk under mpiexec; the log holds an FNV-1a hash of the bytes each read
+    returned).  The device read path (pread -> pinned slabs -> HBM -> unpack kernel) must return the same
+    bytes for the same frame / chunk / row slab: whole chunks, slabs, buffered small chunks."""
+    import re
+    import pgsd.fl as fl
+    gsd = os.path.join(S.GOLDEN, "readback.p%d.gsd" % P)
+    lines = [ln for ln in S.read_log(gsd[:-4] + ".log") if ln.startswith("read ")]
+    f = fl.open(gsd, "r")
+    checked = 0
+    for ln in lines:
+        m = re.match(r"read line=\d+ frame=(\d+) name=(\S+) N=(\d+) M=(\d+) offset=(\d+) all=(\d) rc=(-?\d+) bytes=(\d+) "
+                     r"fnv=([0-9a-f]{16})", ln)
+        frame, name, N, M, off, all_, rc, nbytes, fnv = m.groups()
+        if int(rc) != 0 or int(frame) >= f.nframes:
+            continue
+        if int(all_):
+            t = f.read_chunk_device(int(frame), name, N=int(N), offset=int(off))
+        else:
+            t = f.read_chunk_device(int(frame), name)
+        got = t.cpu().numpy().tobytes()
+        assert len(got) == int(nbytes), ln
+        assert "%016x" % _fnv1a(got) == fnv, ln
+        checked += 1
+    f.close()
+    assert checked >= 10
