@@ -658,7 +658,6 @@ __global__ __launch_bounds__(T) void pack_rows_kernel(const RowsArgs args)
     RowRegs r[U];
     const uint64_t N = args.N;
     const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
-    const uint32_t* order = g.order;
     const uint32_t* src = (const uint32_t*)g.src;
 #pragma unroll
     for (int k = 0; k < U; k++)
@@ -667,10 +666,7 @@ __global__ __launch_bounds__(T) void pack_rows_kernel(const RowsArgs args)
         r[k].hi = u32x4 {0, 0, 0, 0};
         const uint64_t i = base + (uint64_t)k * T;
         if (i < N)
-            {
-            const uint64_t srow = order ? (uint64_t)__builtin_nontemporal_load(order + i) : i;
-            row_load<RW>(src + srow * RW, r[k]);
-            }
+            row_load<RW>(src + i * RW, r[k]);
         }
     const uint32_t n_out = g.n_out;
 #pragma unroll
@@ -1222,15 +1218,15 @@ static bool rows_eligible(const pgsd_pack_job& j, uint64_t N, uint32_t* kind_out
     else
         return false;
     const uint64_t rw = (uint64_t)j.src.src_stride * ssz / 4, nw = (uint64_t)j.M * dsz / 4;
-    const bool dense = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
+    const bool dense = rk == ROWS_BITS && j.src.src_col0 == 0 && j.M == j.src.src_stride;
     if (!dense && ((rw != 1 && rw != 2 && rw != 3 && rw != 4 && rw != 6 && rw != 8) || nw > ROWS_MAX_WORDS))
         return false;
     if ((((uintptr_t)j.dst | (uintptr_t)j.src.src) & 15) != 0)
         return false;
     // gathers (tag order through a permutation) stay with the LDS-tiled kernel: one random 16-byte row per
-    // lane costs a whole line either way, and its four-deep row fetches measured faster (417 vs 480-510 us
-    // for two float4 arrays of 10 M rows)
-    if (j.src.order != nullptr && !getenv("PGSD_PACK_ROWS_GATHER"))
+    // lane costs a whole memory request either way, and its four-deep row fetches measured faster than a
+    // row-per-lane gather (417 vs 480-510 us for two float4 arrays of 10 M rows, profiles/r02_pack_ab.jsonl)
+    if (j.src.order != nullptr)
         return false;
     if (N >= (1ull << 31)) // one lane per row (or per U rows): keeps the grid's x extent below 2^32 threads
         return false;
@@ -1290,8 +1286,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                         continue;
                     const uint32_t ssz = (uint32_t)sizeof_type(j.src.src_type), dsz = (uint32_t)sizeof_type(j.dst_type);
                     const uint32_t rw = j.src.src_stride * ssz / 4;
-                    const bool dense
-                        = rk == ROWS_BITS && j.src.order == nullptr && j.src.src_col0 == 0 && j.M == j.src.src_stride;
+                    const bool dense = rk == ROWS_BITS && j.src.src_col0 == 0 && j.M == j.src.src_stride;
                     if (dense != (pass == 1))
                         continue;
                     if (!dense && cls_rw != 0 && rw != cls_rw)
@@ -1300,7 +1295,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                     if (!dense)
                         for (uint32_t k = 0; k < a.n_groups; k++)
                             if (a.g[k].copy_vecs == 0 && a.g[k].copy_tail == 0 && a.g[k].src == j.src.src
-                                && a.g[k].order == j.src.order && a.g[k].n_out < PACK_MAX_OUT)
+                                && a.g[k].n_out < PACK_MAX_OUT)
                                 gi = (int)k;
                     if (gi < 0)
                         {
@@ -1309,7 +1304,6 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
                         gi = (int)a.n_groups++;
                         RowsGroup& g = a.g[gi];
                         g.src = j.src.src;
-                        g.order = j.src.order;
                         g.row_words = rw;
                         if (dense)
                             {

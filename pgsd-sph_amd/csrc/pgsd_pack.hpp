@@ -99,7 +99,6 @@ struct RowsOut
 struct RowsGroup
     {
     const void* src;
-    const uint32_t* order; // gather index or nullptr
     uint64_t copy_vecs;    // dense same-type copy: 16-byte vectors to move (0 = row mode)
     uint32_t copy_tail;    // ... and bytes behind the last whole vector
     uint32_t row_words;    // dwords per source row

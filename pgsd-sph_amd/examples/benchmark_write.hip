@@ -10,9 +10,12 @@
 //                           MPI_Allgather of benchmark-write.cc:39-45), placement, copies, writes, index
 // (pgsd_set_frame_exchange; pass "perchunk" as 4th argument for one exchange per chunk and the caller-side
 // pgsd_partition_rows instead) and prints MB/s the way the reference's benchmark does, as one JSON line on rank 0.
+// With "rccl" as 5th argument the ranks bootstrap the library's RCCL communicator themselves -- rank 0's
+// ncclUniqueId travels over the shm communicator they met on -- and every exchange of the run is an
+// ncclAllGather over xGMI: the path a C++ caller (HOOMD-SPH's dump writer) takes without MPI or torch.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [perchunk]
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk] [shm|rccl]
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -61,6 +64,18 @@ int main(int argc, char** argv)
         return 1;
         }
     (void)hipSetDevice(rank % ndev);
+    const char* comm_name = P > 1 ? "shm" : "self";
+    if (argc > 5 && strcmp(argv[5], "rccl") == 0)
+        {
+        // 128-byte id from rank 0 to everybody over the communicator of the launch, then switch
+        unsigned char id[128] = {0};
+        if (rank == 0)
+            CHECK(pgsd_comm_rccl_unique_id(id));
+        std::vector<unsigned char> all((size_t)P * sizeof(id));
+        CHECK(pgsd_comm_allgather(id, all.data(), sizeof(id)));
+        CHECK(pgsd_comm_init_rccl(all.data(), rank, P, rank % ndev));
+        comm_name = "rccl";
+        }
 
     uint64_t row0, n_global;
     std::vector<uint64_t> counts((size_t)P);
@@ -118,10 +133,10 @@ int main(int argc, char** argv)
         {
         printf("{\"ranks\": %d, \"particles_per_rank\": %llu, \"frames\": %d, \"seconds\": %.4f, \"MBps\": %.1f, "
                "\"pack_launches\": %llu, \"written_bytes_rank0\": %llu, \"exchange\": \"%s\", "
-               "\"collectives_rank0\": %llu}\n",
+               "\"collectives_rank0\": %llu, \"comm\": \"%s\"}\n",
                P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
                (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes,
-               batched ? "one per frame" : "one per chunk", collectives);
+               batched ? "one per frame" : "one per chunk", collectives, comm_name);
         unlink(path);
         }
     pgsd_comm_finalize();

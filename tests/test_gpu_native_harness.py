@@ -1,0 +1,55 @@
+"""The native harness (pgsd-sph_amd/examples/benchmark_write.hip: C ABI only, no Python in the data path) --
+the counterpart of the reference's pgsd/scripts/benchmark-write.cc -- in the ways a C++ caller would run it."""
+import json
+import os
+import subprocess
+import uuid
+
+import pytest
+
+import product
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(product.CSRC, "build", "benchmark_write")
+
+
+def run(args, env_extra, timeout=300):
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([EXE] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-1500:]
+    return p.stdout
+
+
+def test_single_rank_batched_and_per_chunk(tmp_path):
+    product.build()
+    for mode in ("batched", "perchunk"):
+        out = run([200000, 4, str(tmp_path / (mode + ".gsd")), mode], {"PGSD_RANK": "0", "PGSD_NRANKS": "1"})
+        d = json.loads(out.strip().splitlines()[-1])
+        assert d["ranks"] == 1 and d["frames"] == 4 and d["pack_launches"] == 5
+        assert d["written_bytes_rank0"] == 5 * 200000 * 28 and d["MBps"] > 0
+
+
+def test_single_rank_over_the_librarys_rccl_communicator(tmp_path):
+    """the C++ bootstrap: unique id -> pgsd_comm_init_rccl, every later exchange is an ncclAllGather"""
+    product.build()
+    out = run([100000, 3, str(tmp_path / "rccl.gsd"), "batched", "rccl"], {"PGSD_RANK": "0", "PGSD_NRANKS": "1"})
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["comm"] == "rccl" and d["written_bytes_rank0"] == 4 * 100000 * 28
+
+
+def test_two_ranks_share_the_gpu_one_exchange_per_frame(tmp_path):
+    product.build()
+    shm = "pgsdnative_%s" % uuid.uuid4().hex[:10]
+    path = str(tmp_path / "two.gsd")
+    procs = [subprocess.Popen([EXE, "150000", "4", path, "batched"],
+                              env=dict(os.environ, PGSD_RANK=str(r), PGSD_NRANKS="2", PGSD_SHM_NAME=shm),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-1500:]
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["ranks"] == 2 and d["exchange"] == "one per frame" and d["comm"] == "shm"
+    # create/open (2) + the row-count allgather the harness makes for its report + 5 frames x ONE exchange
+    # (+ the barriers of the timing fence, which do not go through the handle)
+    assert d["collectives_rank0"] == 2 + 5, d
