@@ -50,6 +50,7 @@ def test_two_ranks_share_the_gpu_one_exchange_per_frame(tmp_path):
         assert p.returncode == 0, e[-1500:]
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["ranks"] == 2 and d["exchange"] == "one per frame" and d["comm"] == "shm"
-    # create/open (2) + the row-count allgather the harness makes for its report + 5 frames x ONE exchange
-    # (+ the barriers of the timing fence, which do not go through the handle)
+    # the handle's own collectives: create/open (2) + 5 frames x ONE exchange (the harness's row-count
+    # allgather for its report and its timing barriers go through the default communicator, not the handle;
+    # the barrier pgsd_close makes up comes after the count was read)
     assert d["collectives_rank0"] == 2 + 5, d
