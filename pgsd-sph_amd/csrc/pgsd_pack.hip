@@ -902,6 +902,119 @@ template<bool W32> __global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_
         }
     }
 
+// ------------------------------------------------------------------ row-per-lane unpack (Scalar4 destinations)
+// Inverse of pack_rows_kernel for the restart path's common shape: a float4-like destination array fed by
+// one or two dense chunks (position.xyz + the type id into position.w, velocity.xyz + mass).  Lane i loads
+// row i of each chunk (12 bytes + 4 bytes: contiguous pieces, consecutive lanes consecutive rows), and
+// stores ONE 16-byte row (two for a double4 destination restored from f32 chunks).  No LDS, no barrier;
+// blockIdx.y = destination array; dense same-type arrays ride along as 16-byte copies.  Measured in the lab
+// (tools/pack_lab.hip, profiles/r02_lab_unpack.jsonl): 100 us for position + id + velocity + mass of 10 M
+// particles where the LDS-tiled unpack needs 113 us.  A first, fully generic version of this kernel (run-time
+// chunk lists and widths) was no faster than the tiled one; the static hot path is what pays.
+template<bool F64> __device__ __forceinline__ void unrows_store(uint32_t* drow, const uint32_t* w, uint32_t nw, uint32_t col0)
+    {
+    // nw source dwords (f32 / 32-bit integers) -> destination elements col0 .. col0+nw
+    if constexpr (!F64)
+        {
+        uint32_t c[ROWS_MAX_WORDS] = {w[0], w[1], w[2], w[3], 0, 0, 0, 0};
+        row_store<4>(drow + col0, c, nw);
+        }
+    else
+        {
+        uint32_t c[ROWS_MAX_WORDS];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++)
+            {
+            const uint64_t bits = (uint64_t)__double_as_longlong((double)__uint_as_float(w[e]));
+            c[2 * e] = (uint32_t)bits;
+            c[2 * e + 1] = (uint32_t)(bits >> 32);
+            }
+        row_store<8>(drow + 2 * col0, c, 2 * nw);
+        }
+    }
+
+__device__ __forceinline__ void unrows_load(const uint32_t* p, uint32_t nw, uint32_t (&w)[4])
+    {
+    RowRegs r;
+    r.lo = u32x4 {0, 0, 0, 0};
+    switch (nw)
+        {
+        case 1: row_load<1>(p, r); break;
+        case 2: row_load<2>(p, r); break;
+        case 3: row_load<3>(p, r); break;
+        default: row_load<4>(p, r); break;
+        }
+    w[0] = r.lo.x, w[1] = r.lo.y, w[2] = r.lo.z, w[3] = r.lo.w;
+    }
+
+template<int T, int U, bool F64> __global__ __launch_bounds__(T) void unpack_rows_kernel(const UnrowsArgs args)
+    {
+    const UnrowsGroup& g = args.g[blockIdx.y];
+    if (g.copy_vecs != 0 || g.copy_tail != 0)
+        {
+        // dense same-type array: the chunk IS the array
+        const u32x4* src = (const u32x4*)g.a;
+        u32x4* dst = (u32x4*)g.dst;
+        const uint64_t nvec = g.copy_vecs;
+        const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+        const uint64_t first = (uint64_t)blockIdx.x * per;
+        const uint64_t last = first + per < nvec ? first + per : nvec;
+        for (uint64_t v = first + threadIdx.x; v < last; v += T)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+        if (blockIdx.x == 0 && threadIdx.x < g.copy_tail)
+            ((char*)dst)[nvec * 16 + threadIdx.x] = ((const char*)src)[nvec * 16 + threadIdx.x];
+        return;
+        }
+    const uint64_t N = args.N;
+    const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
+    constexpr uint32_t DW = F64 ? 8 : 4;
+    uint32_t* dst = (uint32_t*)g.dst;
+    const uint32_t* a = (const uint32_t*)g.a;
+    const uint32_t* b = (const uint32_t*)g.b;
+    if (g.a_nw == 3 && g.a_col0 == 0 && b != nullptr && g.b_nw == 1 && g.b_col0 == 3)
+        {
+        // the hot shape: xyz from one chunk, w from another, whole rows out
+        u32x3 xyz[U];
+        uint32_t w[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * T;
+            if (i < N)
+                {
+                xyz[k] = __builtin_nontemporal_load((const u32x3_a4*)(a + i * 3));
+                w[k] = __builtin_nontemporal_load(b + i);
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * T;
+            if (i < N)
+                {
+                const uint32_t c[4] = {xyz[k].x, xyz[k].y, xyz[k].z, w[k]};
+                unrows_store<F64>(dst + i * DW, c, 4, 0);
+                }
+            }
+        return;
+        }
+    // any other one- or two-chunk shape: each chunk's elements go to their columns
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t i = base + (uint64_t)k * T;
+        if (i >= N)
+            continue;
+        uint32_t wa[4], wb[4] = {0, 0, 0, 0};
+        unrows_load(a + i * g.a_nw, g.a_nw, wa);
+        if (b != nullptr)
+            unrows_load(b + i * g.b_nw, g.b_nw, wb);
+        unrows_store<F64>(dst + i * DW, wa, g.a_nw, g.a_col0);
+        if (b != nullptr)
+            unrows_store<F64>(dst + i * DW, wb, g.b_nw, g.b_col0);
+        }
+    }
+
 // ------------------------------------------------------------------ select (compaction)
 #define SEL_THREADS 256
 #define SEL_PER_THREAD 16
@@ -1509,6 +1622,45 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         }
     return PGSD_SUCCESS;
     }
+// ---- row-per-lane unpack: which destination arrays it takes and how it is launched
+struct UnrowsPlan
+    {
+    UnrowsArgs args;
+    bool f64 = false;
+    };
+
+static void launch_unrows(const UnrowsPlan& p, uint64_t N, hipStream_t stream)
+    {
+    // measured (profiles/r02_lab_unpack.jsonl, r02_unpack_rows_final.jsonl): thin workgroups; 64 x 2 rows
+    // 102.4-103.0 us, 128 x 1 104.6-105.0 us, 256 x 2 105.9-106.0 us (10 M particles, stream events)
+    int T = 64, U = 2;
+    if (const char* e = getenv("PGSD_UNPACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
+        (void)sscanf(e, "%dx%d", &T, &U);
+    UnrowsArgs a = p.args;
+    a.n_blocks = (N + (uint64_t)T * U - 1) / ((uint64_t)T * U);
+    const dim3 grid((unsigned)a.n_blocks, a.n_groups);
+#define UNROWS_LAUNCH(TT, UU)                                                                                  \
+    if (T == TT && U == UU)                                                                                    \
+        {                                                                                                      \
+        if (p.f64)                                                                                             \
+            hipLaunchKernelGGL((unpack_rows_kernel<TT, UU, true>), grid, dim3(TT), 0, stream, a);              \
+        else                                                                                                   \
+            hipLaunchKernelGGL((unpack_rows_kernel<TT, UU, false>), grid, dim3(TT), 0, stream, a);             \
+        return;                                                                                                \
+        }
+    UNROWS_LAUNCH(128, 1)
+    UNROWS_LAUNCH(256, 1)
+    UNROWS_LAUNCH(256, 2)
+    UNROWS_LAUNCH(128, 2)
+    a.n_blocks = (N + 127) / 128;
+    const dim3 grid1((unsigned)a.n_blocks, a.n_groups);
+    if (p.f64)
+        hipLaunchKernelGGL((unpack_rows_kernel<64, 2, true>), grid1, dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((unpack_rows_kernel<64, 2, false>), grid1, dim3(64), 0, stream, a);
+#undef UNROWS_LAUNCH
+    }
+
 // One batch of <= UNPACK_MAX_JOBS validated chunks -> one launch.
 static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, hipStream_t stream)
     {
@@ -1643,6 +1795,92 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
         }
     // chunks of one destination array next to each other (their relative order is kept)
     std::stable_sort(all.begin(), all.end(), [](const UnpackJob& a, const UnpackJob& b) { return (uintptr_t)a.dst < (uintptr_t)b.dst; });
+    // 1. destination arrays the row-per-lane kernel takes: rows of four 4-byte elements (or four doubles
+    //    restored from f32 chunks) fed by one or two chunks of 4-byte elements on disjoint columns, no
+    //    scatter index; plus dense same-type arrays (the chunk IS the array).  One launch per conversion
+    //    class; everything else goes to the LDS-tiled kernel below.
+    const char* force = getenv("PGSD_UNPACK_KERNEL");
+    if (N < (1ull << 31) && !(force && strcmp(force, "tiles") == 0))
+        {
+        std::vector<bool> taken(all.size(), false);
+        for (int f64 = 0; f64 < 2; f64++)
+            {
+            while (true)
+                {
+                UnrowsPlan plan;
+                memset(&plan.args, 0, sizeof(plan.args));
+                plan.args.N = N;
+                plan.f64 = f64 != 0;
+                for (size_t i = 0; i < all.size();)
+                    {
+                    size_t e = i; // [i, e) = the chunks of one destination array (sorted by dst, order kept)
+                    while (e < all.size() && all[e].dst == all[i].dst)
+                        e++;
+                    const UnpackJob& j0 = all[i];
+                    const size_t n = e - i;
+                    bool ok = !taken[i] && n <= 2 && plan.args.n_groups < ROWS_MAX_GROUPS && (((uintptr_t)j0.dst) & 15) == 0;
+                    for (size_t k = i; k < e && ok; k++)
+                        {
+                        const UnpackJob& j = all[k];
+                        ok = j.order == nullptr && j.dst_stride == j0.dst_stride && j.dsz == j0.dsz
+                             && (((uintptr_t)j.src) & 15) == 0;
+                        }
+                    // a dense array of the chunk's own type (any element size, any row width): a plain copy
+                    const bool dense = ok && n == 1 && j0.kind == PACK_BITS && j0.ssz == j0.dsz && j0.dst_col0 == 0
+                                       && j0.M == j0.dst_stride;
+                    if (dense)
+                        ok = f64 == 0; // rides along in the launch of the first pass
+                    else if (ok)
+                        {
+                        ok = j0.dst_stride == 4 && (f64 ? j0.dsz == 8 : j0.dsz == 4);
+                        for (size_t k = i; k < e && ok; k++)
+                            ok = all[k].ssz == 4 && all[k].kind == (uint32_t)(f64 ? PACK_F2F : PACK_BITS) && all[k].M <= 4;
+                        if (ok && n == 2) // disjoint columns: no "later chunk wins" question inside a row
+                            ok = all[i].dst_col0 + all[i].M <= all[i + 1].dst_col0
+                                 || all[i + 1].dst_col0 + all[i + 1].M <= all[i].dst_col0;
+                        }
+                    if (ok)
+                        {
+                        UnrowsGroup& g = plan.args.g[plan.args.n_groups++];
+                        g.dst = j0.dst;
+                        g.a = j0.src;
+                        if (dense)
+                            {
+                            const uint64_t bytes = N * (uint64_t)j0.M * j0.ssz;
+                            g.copy_vecs = bytes >> 4;
+                            g.copy_tail = (uint32_t)(bytes & 15);
+                            }
+                        else
+                            {
+                            // `a` = the chunk of the lower columns (xyz before w: the kernel's static hot shape)
+                            const UnpackJob& lo = (n == 2 && all[i + 1].dst_col0 < j0.dst_col0) ? all[i + 1] : j0;
+                            g.a = lo.src;
+                            g.a_nw = lo.M;
+                            g.a_col0 = lo.dst_col0;
+                            if (n == 2)
+                                {
+                                const UnpackJob& hi = (&lo == &j0) ? all[i + 1] : j0;
+                                g.b = hi.src;
+                                g.b_nw = hi.M;
+                                g.b_col0 = hi.dst_col0;
+                                }
+                            }
+                        for (size_t k = i; k < e; k++)
+                            taken[k] = true;
+                        }
+                    i = e;
+                    }
+                if (plan.args.n_groups == 0)
+                    break;
+                launch_unrows(plan, N, stream);
+                }
+            }
+        std::vector<UnpackJob> rest;
+        for (size_t i = 0; i < all.size(); i++)
+            if (!taken[i])
+                rest.push_back(all[i]);
+        all.swap(rest);
+        }
     std::vector<UnpackJob> batch;
     uint32_t sum_rowbytes = 0;
     for (size_t i = 0; i < all.size(); i++)

@@ -171,6 +171,27 @@ struct UnpackArgs
     UnpackGroup g[UNPACK_MAX_GROUPS];
     };
 
+// ---- row-per-lane unpack (unpack_rows_kernel): Scalar4 / double4 destination arrays fed by one or two chunks
+struct UnrowsGroup
+    {
+    void* dst;          // destination array: rows of 4 elements (float4-like; double4 when converting f32 -> f64)
+    const void* a;      // first chunk (dense rows of a_nw dwords), never null
+    const void* b;      // second chunk or nullptr
+    uint32_t a_nw, a_col0, b_nw, b_col0; // dwords per chunk row / first destination ELEMENT
+    uint64_t copy_vecs; // dense same-type array riding along: 16-byte vectors to copy from `a` to `dst` (0 = row mode)
+    uint32_t copy_tail;
+    uint32_t pad;
+    };
+
+struct UnrowsArgs
+    {
+    uint64_t N;
+    uint64_t n_blocks;
+    uint32_t n_groups;
+    uint32_t pad;
+    UnrowsGroup g[ROWS_MAX_GROUPS];
+    };
+
 // Enqueue the unpack of `n_jobs` chunks of N rows each on `stream`. Returns a pgsd_error.
 int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err);
 

@@ -9,6 +9,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["rows", "tiles"], autouse=True)
+def unpack_kernel_family(request, monkeypatch):
+    """The read-path tests run through both unpack kernels: row-per-lane (Scalar4 destinations, dense arrays)
+    and the LDS-tiled one, which takes everything when PGSD_UNPACK_KERNEL=tiles."""
+    monkeypatch.setenv("PGSD_UNPACK_KERNEL", request.param)
+    return request.param
+
+
+@pytest.fixture(params=["rows", "tiles"], autouse=True)
 def pack_kernel_family(request, monkeypatch):
     """Every parity test runs through both kernel families: the row-per-lane kernel (the default for 4- and
     8-byte elements) and the LDS-tiled kernel, which takes everything when PGSD_PACK_KERNEL=tiles."""

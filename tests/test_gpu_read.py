@@ -11,6 +11,14 @@ import scenario as S
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["rows", "tiles"], autouse=True)
+def unpack_kernel_family(request, monkeypatch):
+    """The read-path tests run through both unpack kernels: row-per-lane (Scalar4 destinations, dense arrays)
+    and the LDS-tiled one, which takes everything when PGSD_UNPACK_KERNEL=tiles."""
+    monkeypatch.setenv("PGSD_UNPACK_KERNEL", request.param)
+    return request.param
+
 torch = pytest.importorskip("torch")
 
 

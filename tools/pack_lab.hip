@@ -358,6 +358,81 @@ __global__ __launch_bounds__(256) void lds96_kernel(const u32x4* __restrict__ po
         }
     }
 
+// ---------------------------------------------------------------- unpack direction (read path)
+// chunks (N x 3 position, N x 1 id, N x 3 velocity, N x 1 mass) -> two Scalar4 arrays, 640 MB at 10 M rows
+// (a) row per lane: 12-byte + 4-byte loads, 16-byte stores
+template<int T, int U>
+__global__ __launch_bounds__(T) void unrows_kernel(const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cid,
+                                                   const uint32_t* __restrict__ cvel, const uint32_t* __restrict__ cmass,
+                                                   u32x4* __restrict__ pos4, u32x4* __restrict__ vel4, uint64_t N)
+    {
+    const bool second = blockIdx.y != 0; // y = destination array
+    const uint32_t* c3 = second ? cvel : cpos;
+    const uint32_t* c1 = second ? cmass : cid;
+    u32x4* dst = second ? vel4 : pos4;
+    const uint64_t base = (uint64_t)blockIdx.x * (T * U) + threadIdx.x;
+    u32x3 a[U];
+    uint32_t w[U];
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t i = base + (uint64_t)k * T;
+        if (i < N)
+            {
+            a[k] = __builtin_nontemporal_load((const u32x3*)(c3 + i * 3));
+            w[k] = __builtin_nontemporal_load(c1 + i);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        {
+        const uint64_t i = base + (uint64_t)k * T;
+        if (i < N)
+            {
+            u32x4 o = {a[k].x, a[k].y, a[k].z, w[k]};
+            __builtin_nontemporal_store(o, dst + i);
+            }
+        }
+    }
+
+// (b) wave-private LDS: every load is a linear 16-byte vector of the dense chunk stream (3 of position + 1 of
+// the id per 256 rows and lane), rows are read back as 12-byte + 4-byte pieces; no workgroup barrier
+__global__ __launch_bounds__(256) void unlds_kernel(const u32x4* __restrict__ cpos, const u32x4* __restrict__ cid,
+                                                    const u32x4* __restrict__ cvel, const u32x4* __restrict__ cmass,
+                                                    u32x4* __restrict__ pos4, u32x4* __restrict__ vel4, uint64_t N)
+    {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][1024];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* L = lds_all[wave];
+    const bool second = blockIdx.y != 0;
+    const u32x4* c3 = second ? cvel : cpos;
+    const u32x4* c1 = second ? cmass : cid;
+    u32x4* dst = second ? vel4 : pos4;
+    const uint64_t step = (uint64_t)blockIdx.x * 4 + wave; // 256 rows per wave
+    if (step * 256 >= N)
+        return;
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        v[k] = __builtin_nontemporal_load(c3 + step * 192 + k * 64 + lane);
+    v[3] = __builtin_nontemporal_load(c1 + step * 64 + lane);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        *(u32x4*)(L + (k * 64 + lane) * 4) = v[k];
+    *(u32x4*)(L + 768 + lane * 4) = v[3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        {
+        const uint32_t r = k * 64 + lane;
+        const u32x3 a = *(const u32x3*)(L + r * 3);
+        u32x4 o = {a.x, a.y, a.z, L[768 + r]};
+        __builtin_nontemporal_store(o, dst + step * 256 + r);
+        }
+    }
+
 // ---------------------------------------------------------------- harness
 struct Set
     {
@@ -596,6 +671,111 @@ int main(int argc, char** argv)
         },                                                                                                   \
         pack_moved, pack_algo, true)
     LDS96(true, 0);
+
+    // ---- unpack direction: the packed chunks of set k -> Scalar4 arrays (reusing pos/vel of set k+1 as
+    //      destinations); 640 MB moved at 10 M rows.  mass chunk = the id buffer of another set (values do
+    //      not matter for timing; verification checks the xyz + id words).
+        {
+        uint32_t* mass;
+        CK(hipMalloc(&mass, N * 4));
+        CK(hipMemset(mass, 0x3f, N * 4));
+        // reference chunks for every set: packed from its own pos/vel
+        for (auto& st : sets)
+            hipLaunchKernelGGL(ref_kernel, dim3(4096), dim3(256), 0, 0, st.pos, st.vel, st.opos, st.ovel, st.oid, N);
+        CK(hipDeviceSynchronize());
+        std::vector<Set> dsts(NSETS);
+        for (auto& d : dsts)
+            {
+            CK(hipMalloc(&d.pos, N * 16));
+            CK(hipMalloc(&d.vel, N * 16));
+            }
+        auto check_un = [&](int k) -> unsigned long long
+        {
+            // pos4 of the result must equal the source pos (xyz + id in w); vel4.xyz the source vel
+            CK(hipMemset(bad, 0, 8));
+            hipLaunchKernelGGL(cmp_kernel, dim3(2048), dim3(256), 0, 0, dsts[k].pos, sets[k].pos, N * 4, bad);
+            unsigned long long h = 0;
+            CK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+            return h;
+        };
+        const double un_moved = (double)N * 64.0;
+        auto run_un = [&](const std::string& name, auto&& launch)
+        {
+            CK(hipMemset(dsts[0].pos, 0xff, N * 16));
+            for (int i = 0; i < 3; i++)
+                launch(i % NSETS, (hipEvent_t) nullptr, (hipEvent_t) nullptr);
+            CK(hipDeviceSynchronize());
+            unsigned long long nbad = check_un(0);
+            std::vector<float> t;
+            for (int i = 0; i < reps; i++)
+                {
+                launch(i % NSETS, e0, e1);
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t.push_back(ms * 1000.f);
+                }
+            const double m = med(t), mn = *std::min_element(t.begin(), t.end());
+            printf("{\"kernel\": \"%s\", \"us_med\": %.2f, \"us_min\": %.2f, \"moved_TBps\": %.3f, "
+                   "\"frac_of_8TBps\": %.4f, \"mismatches\": %llu}\n",
+                   name.c_str(), m, mn, un_moved / m / 1e6, un_moved / m / 1e6 / 8.0, nbad);
+            fflush(stdout);
+        };
+#define UNROWS(T, U)                                                                                          \
+    if (want("unrows T=" #T " U=" #U))                                                                        \
+    run_un("unrows T=" #T " U=" #U,                                                                           \
+           [&](int k, hipEvent_t a, hipEvent_t b)                                                             \
+           {                                                                                                  \
+               dim3 grid((unsigned)((N + (T) * (U)-1) / ((T) * (U))), 2);                                     \
+               hipExtLaunchKernelGGL((unrows_kernel<T, U>), grid, dim3(T), 0, 0, a, b, 0, sets[k].opos, sets[k].oid, \
+                                     sets[k].ovel, mass, (u32x4*)dsts[k].pos, (u32x4*)dsts[k].vel, N);        \
+           })
+        UNROWS(256, 2);
+        UNROWS(64, 2);
+        UNROWS(128, 1);
+        if (want("unlds"))
+            run_un("unlds (wave-private LDS, 16-byte loads)",
+                   [&](int k, hipEvent_t a, hipEvent_t b)
+                   {
+                       dim3 grid((unsigned)((N / 256 + 3) / 4), 2);
+                       hipExtLaunchKernelGGL(unlds_kernel, grid, dim3(256), 0, 0, a, b, 0, (const u32x4*)sets[k].opos,
+                                             (const u32x4*)sets[k].oid, (const u32x4*)sets[k].ovel, (const u32x4*)mass,
+                                             (u32x4*)dsts[k].pos, (u32x4*)dsts[k].vel, N);
+                   });
+        if (so && want("product unpack"))
+            {
+            void* lib = dlopen(so, RTLD_NOW);
+            struct field_dst
+                {
+                void* dst;
+                const uint32_t* order;
+                uint32_t dst_type, dst_stride, dst_col0, bitcast;
+                };
+            struct unpack_job
+                {
+                const void* src;
+                uint32_t src_type, M;
+                field_dst dst;
+                };
+            auto unpack_fields = lib ? (int (*)(uint32_t, const unpack_job*, uint64_t, void*))dlsym(lib, "pgsd_unpack_fields")
+                                     : nullptr;
+            if (unpack_fields)
+                run_un("product pgsd_unpack_fields (LDS-tiled)",
+                       [&](int k, hipEvent_t a, hipEvent_t b)
+                       {
+                           unpack_job j[4] = {{sets[k].opos, 9, 3, {dsts[k].pos, nullptr, 9, 4, 0, 0}},
+                                              {sets[k].oid, 3, 1, {dsts[k].pos, nullptr, 9, 4, 3, 1}},
+                                              {sets[k].ovel, 9, 3, {dsts[k].vel, nullptr, 9, 4, 0, 0}},
+                                              {mass, 9, 1, {dsts[k].vel, nullptr, 9, 4, 3, 0}}};
+                           if (a)
+                               CK(hipEventRecord(a, 0));
+                           if (unpack_fields(4, j, N, nullptr) != 0)
+                               exit(5);
+                           if (b)
+                               CK(hipEventRecord(b, 0));
+                       });
+            }
+        }
 
     if (so)
         {
