@@ -218,9 +218,33 @@ class Frame(object):
         self.constraints.validate()
 
 
+class _FrameCursor(object):
+    """What ``iter()`` hands out for a trajectory or a subset of one (the role of hoomd.py:471-488):
+    it knows how many frames it covers (``len``), yields them in order, and asking it for an iterator
+    again starts a fresh pass over the same frames -- so ``list(cursor)`` can be taken more than once."""
+
+    def __init__(self, trajectory, indices):
+        self._trajectory = trajectory
+        self._indices = indices
+        self._at = 0
+
+    def __len__(self):
+        return len(self._indices)
+
+    def __iter__(self):
+        return _FrameCursor(self._trajectory, self._indices)
+
+    def __next__(self):
+        if self._at >= len(self._indices):
+            raise StopIteration
+        i = self._indices[self._at]
+        self._at += 1
+        return self._trajectory[i]
+
+
 class _FrameSubset(object):
     """The frames of a trajectory picked by a sequence of indices: what slicing a
-    `HOOMDTrajectory` returns (the role of hoomd.py:470-512).  Supports ``len``, iteration,
+    `HOOMDTrajectory` returns (the role of hoomd.py:491-512).  Supports ``len``, iteration,
     integer indexing and further slicing; frames are read when they are asked for."""
 
     def __init__(self, trajectory, indices):
@@ -231,7 +255,7 @@ class _FrameSubset(object):
         return len(self._indices)
 
     def __iter__(self):
-        return (self._trajectory[i] for i in self._indices)
+        return _FrameCursor(self._trajectory, self._indices)
 
     def __getitem__(self, key):
         picked = self._indices[key]
@@ -339,20 +363,22 @@ class HOOMDTrajectory(object):
                 names += list(container._extra_default_value)
             for name in names:
                 if (path, name) == ('particles', 'N'):
-                    plan.append((path, name, False))      # decided below from the global count
+                    # None = "as in frame 0": no count chunk; decided below from the global count otherwise
+                    plan.append((path, name, frame.particles.N is not None))
                 else:
                     plan.append((path, name, self._should_write(path, name, frame, None)))
+        n_local = int(frame.particles.N) if frame.particles.N is not None else 0
         if frame.part_dist is not None:
             part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
             if part_dist.shape[0] != size:
                 raise ValueError("part_dist must have one entry per rank")
         else:
-            part_dist = numpy.array([int(frame.particles.N)], dtype=numpy.uint64)
+            part_dist = numpy.array([n_local], dtype=numpy.uint64)
         if size > 1:
             from ._lib import lib
             import ctypes
             mine = numpy.zeros(8 + len(plan), dtype=numpy.uint8)
-            mine[:8] = numpy.array([int(frame.particles.N)], dtype=numpy.uint64).view(numpy.uint8)
+            mine[:8] = numpy.array([n_local], dtype=numpy.uint64).view(numpy.uint8)
             mine[8:] = [1 if w else 0 for _, _, w in plan]
             allb = numpy.zeros(size * len(mine), dtype=numpy.uint8)
             rc = lib.pgsd_comm_allgather(mine.ctypes.data_as(ctypes.c_void_p), allb.ctypes.data_as(ctypes.c_void_p),
@@ -365,7 +391,7 @@ class HOOMDTrajectory(object):
             agreed = allb[:, 8:].max(axis=0)
             plan = [(p, n, bool(a)) for (p, n, _), a in zip(plan, agreed)]
         n_global = int(part_dist.sum())
-        plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') else w)
+        plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') and w else w)
                 for p, n, w in plan]
 
         # 2. write, in the reference's chunk order; device fields go out in one fused launch
@@ -382,7 +408,7 @@ class HOOMDTrajectory(object):
                 if data is None:
                     # another rank needs the chunk: contribute this rank's rows of the default
                     default = container._default_value.get(name, container._extra_default_value.get(name))
-                    data = numpy.empty([frame.particles.N] + ([M] if M > 1 else []), dtype=dt)
+                    data = numpy.empty([n_local] + ([M] if M > 1 else []), dtype=dt)
                     data[...] = default
                 if _is_device(data):
                     f = data if isinstance(data, fl.DeviceField) else fl.DeviceField.from_tensor(data, out_dtype=dt)
@@ -690,7 +716,7 @@ class HOOMDTrajectory(object):
         return self._read_frame(idx)
 
     def __iter__(self):
-        return iter(_FrameSubset(self, range(len(self))))
+        return _FrameCursor(self, range(len(self)))
 
     def __enter__(self):
         return self
