@@ -25,6 +25,10 @@
  *       N_global=N, offset=0, global_size=N*M
  *
  * Script grammar (one command per line, '#' starts a comment):
+ *   prefill <file>                 (rank 0 copies <file> -- relative names are looked up in ../files beside the
+ *                                   script's directory -- to the output path, then all ranks meet at a barrier:
+ *                                   scenarios that start from an existing file, e.g. the reference's GSD v1.0
+ *                                   test fixture, continue with `open`)
  *   create <application> <schema> <major> <minor> <rw|append> <excl 0|1>
  *   open <rw|ro|append>
  *   seed <u64>
@@ -170,6 +174,53 @@ static void dist_counts(const char* dist, uint64_t* counts)
         }
     }
 
+static void all_ranks_meet(void)
+    {
+#if defined(PGSD_DRIVER_REF) || defined(PGSD_DRIVER_MPI)
+    MPI_Barrier(MPI_COMM_WORLD);
+#else
+    pgsd_comm_barrier();
+#endif
+    }
+
+/* start the output file as a copy of a fixture */
+static int prefill(const char* script, const char* name, const char* out)
+    {
+    int rc = 0;
+    if (g_rank == 0)
+        {
+        char src[2048];
+        const char* slash = strrchr(script, '/');
+        if (name[0] == '/')
+            snprintf(src, sizeof(src), "%s", name);
+        else if (slash)
+            snprintf(src, sizeof(src), "%.*s/../files/%s", (int)(slash - script), script, name);
+        else
+            snprintf(src, sizeof(src), "../files/%s", name);
+        FILE* in = fopen(src, "rb");
+        FILE* o = in ? fopen(out, "wb") : NULL;
+        if (!in || !o)
+            {
+            perror(in ? out : src);
+            rc = 2;
+            }
+        else
+            {
+            char buf[65536];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof(buf), in)) > 0)
+                if (fwrite(buf, 1, n, o) != n)
+                    rc = 2;
+            }
+        if (in)
+            fclose(in);
+        if (o && fclose(o) != 0)
+            rc = 2;
+        }
+    all_ranks_meet();
+    return rc;
+    }
+
 static enum pgsd_open_flag parse_flag(const char* s)
     {
     if (strcmp(s, "rw") == 0)
@@ -244,7 +295,12 @@ int main(int argc, char** argv)
             continue;
         int rc = 0;
         const char* cmd = tok[0];
-        if (strcmp(cmd, "create") == 0 && nt == 7)
+        if (strcmp(cmd, "prefill") == 0 && nt == 2)
+            {
+            if (prefill(argv[1], tok[1], path) != 0)
+                return 2;
+            }
+        else if (strcmp(cmd, "create") == 0 && nt == 7)
             {
             rc = pgsd_create_and_open(&handle, path, tok[1], tok[2],
                                       pgsd_make_version((unsigned)atoi(tok[3]), (unsigned)atoi(tok[4])),

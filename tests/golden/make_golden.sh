@@ -11,11 +11,14 @@ MPIEXEC=${MPIEXEC:-/opt/conda/bin/mpiexec}
 OUT=tests/golden/files
 mkdir -p "$OUT"
 rm -f "$OUT"/*.gsd "$OUT"/*.log
+# the reference's own GSD v1.0 read fixture (data file of its test suite, test_fl.py:613-651);
+# vone_append.scn starts from a copy of it (`prefill`)
+cp /root/reference/pgsd/pgsd/test/test_gsd_v1.gsd "$OUT/reference_test_gsd_v1.gsd"
 declare -A RANKS=(
   [posvelid]="1 2 4 8" [sph_full]="1 2 4 8" [index_expand]="1 2 4 8"
   [zero_rank]="1 2 4 8" [alltypes]="1 3" [names_reloc]="1 2 5" [maxbuf]="1 2 4"
   [reopen]="1 2 4" [midflush]="1 2 3" [benchlike]="1 2 4 8"
-  [defaultargs]="1 2 3 4" [readback]="1 2 4"
+  [defaultargs]="1 2 3 4" [readback]="1 2 4" [vone_append]="1 2 3"
 )
 for scn in tests/golden/scenarios/*.scn; do
   name=$(basename "$scn" .scn)
@@ -25,7 +28,5 @@ for scn in tests/golden/scenarios/*.scn; do
     mv /tmp/golden_$$.gsd "$OUT/$name.p$p.gsd"
   done
 done
-# the reference's own GSD v1.0 read fixture (data file of its test suite, test_fl.py:613-651)
-cp /root/reference/pgsd/pgsd/test/test_gsd_v1.gsd "$OUT/reference_test_gsd_v1.gsd"
 ( cd "$OUT" && sha256sum *.gsd *.log > SHA256SUMS )
 du -sh "$OUT"

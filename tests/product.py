@@ -55,8 +55,10 @@ def batched_script(path, out_path):
     lines = []
     with open(path) as f:
         for line in f:
-            lines.append(line)
             tok = line.split("#", 1)[0].split()
+            if tok and tok[0] == "prefill" and not os.path.isabs(tok[1]):   # looked up beside the ORIGINAL script
+                line = "prefill %s\n" % os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(path)), "..", "files", tok[1]))
+            lines.append(line)
             if tok and (tok[0] == "create" or (tok[0] == "open" and tok[1] != "ro")):
                 lines.append("batch 1\n")
     with open(out_path, "w") as f:

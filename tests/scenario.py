@@ -197,6 +197,10 @@ def run_oracle(script, out_path, P):
                                            lib.oracle_make_version(int(tok[3]), int(tok[4])),
                                            FLAGS[tok[5]], int(tok[6]), ctypes.byref(rc_ref))
             rc = rc_ref.value
+        elif cmd == "prefill":
+            import shutil
+            src = tok[1] if os.path.isabs(tok[1]) else os.path.join(os.path.dirname(os.path.abspath(script)), "..", "files", tok[1])
+            shutil.copyfile(src, out_path)
         elif cmd == "open":
             h = lib.oracle_open(out_path.encode(), P, FLAGS[tok[1]], ctypes.byref(rc_ref))
             rc = rc_ref.value

@@ -269,6 +269,48 @@ def test_read_reference_v1_file():
             assert not f.chunk_exists(5, '0') and not f.chunk_exists(0, '127')
 
 
+@pytest.mark.parametrize("reopen_mode", ["r", "a", "r+"])
+def test_write_to_reference_v1_file(tmp_path, reopen_mode):
+    """test_fl.py:709-785: a v1 file can be written to and stays v1 -- 256 integer names (129 of them new:
+    the name list moves) plus one far too long name, which v1's 64-byte slots cut to 63 bytes.  Checked on
+    the writing handle, after reopening, and with the pure-Python reader.  (The layout of such a file is
+    pinned to the reference's bytes by tests/golden/scenarios/vone_append.scn.)"""
+    import random
+    import shutil
+    path = str(tmp_path / "v1.gsd")
+    shutil.copy(os.path.join(S.GOLDEN, 'reference_test_gsd_v1.gsd'), path)
+    long_name = 'abcdefg' * 1000
+    values = list(range(256)) + [long_name]
+    names = sorted(str(v)[:63] for v in values)
+
+    def payload(v):
+        return np.array([v * 13], dtype=np.int32) if isinstance(v, int) else np.array([len(v), -7], dtype=np.int64)
+
+    def check(f):
+        assert f.pgsd_version == (1, 0)
+        assert sorted(f.find_matching_chunk_names('')) == names
+        order = list(values)
+        random.Random(7).shuffle(order)
+        for v in order:
+            got = f.read_chunk(frame=5, name=str(v)[:63])
+            assert got.dtype == payload(v).dtype
+            np.testing.assert_array_equal(got, payload(v))
+        assert f.read_chunk(frame=3, name='126')[0] == 126 * 13        # the old frames are still there
+        assert not f.chunk_exists(4, '200') and f.chunk_exists(5, '200')
+
+    with fl.open(path, 'r+') as f:
+        assert f.pgsd_version == (1, 0) and f.nframes == 5
+        for v in values:
+            f.write_chunk(name=str(v), data=payload(v))
+        f.end_frame()
+        assert f.nframes == 6
+        check(f)
+    with fl.open(path, reopen_mode) as f:
+        check(f)
+    with pypgsd.PGSDFile(open(path, 'rb')) as f:
+        check(f)
+
+
 def test_zero_size_chunk_in_middle(tmp_gsd):
     """test_fl.py:863-893."""
     with create(tmp_gsd) as f:
