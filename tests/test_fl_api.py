@@ -406,3 +406,54 @@ def test_async_end_frame_on_host_data_is_the_same_file(tmp_path):
             f.frame_sync()
     with open(a, 'rb') as fa, open(b, 'rb') as fb:
         assert fa.read() == fb.read()
+
+
+def test_open_modes(tmp_path):
+    """The open() mode table (fl.pyx:301-317; the walk through the modes is test_fl.py:432-495, with the
+    reference's own mode names: it has no 'wb'/'xb+' spellings): 'x' creates and refuses an existing file,
+    'w' overwrites, 'a' creates a missing file and otherwise appends, 'r+' writes to an existing file, 'r'
+    only reads; writable modes can read what they wrote."""
+    data = np.array([1, 2, 3, 4, 5, 10012], dtype=np.int64)
+    path = str(tmp_path / "modes.gsd")
+    kw = dict(application='test_open', schema='none', schema_version=[1, 2])
+
+    def one_frame(f):
+        f.write_chunk(name='chunk1', data=data)
+        f.end_frame()
+
+    with fl.open(name=path, mode='x', **kw) as f:
+        one_frame(f)
+        np.testing.assert_array_equal(f.read_chunk(0, name='chunk1'), data)
+    with pytest.raises(FileExistsError):
+        fl.open(name=path, mode='x', **kw)
+    with fl.open(name=path, mode='w', **kw) as f:          # starts over
+        assert f.nframes == 0
+        one_frame(f)
+        f.read_chunk(0, name='chunk1')
+    with fl.open(name=path, mode='a', **kw) as f:          # keeps frame 0, adds frame 1
+        assert f.nframes == 1
+        one_frame(f)
+    with fl.open(name=path, mode='r', **kw) as f:
+        assert f.nframes == 2
+        f.read_chunk(0, name='chunk1')
+        f.read_chunk(1, name='chunk1')
+        with pytest.raises(RuntimeError):
+            f.write_chunk(name='chunk1', data=data)
+    with fl.open(name=path, mode='r+', **kw) as f:
+        one_frame(f)
+        for i in range(3):
+            np.testing.assert_array_equal(f.read_chunk(i, name='chunk1'), data)
+    other = str(tmp_path / "fresh.gsd")
+    with fl.open(name=other, mode='a', **kw) as f:         # 'a' on a missing file creates it
+        one_frame(f)
+    with fl.open(name=other, mode='r') as f:
+        assert f.nframes == 1 and f.application == 'test_open'
+    for bad in ('wb', 'xb+', 'rb', 'ab', 'z', ''):
+        with pytest.raises(ValueError):
+            fl.open(name=path, mode=bad, **kw)
+    for mode in ('r', 'r+'):
+        with pytest.raises(FileNotFoundError):
+            fl.open(name=str(tmp_path / "missing.gsd"), mode=mode, **kw)
+    for mode in ('w', 'x'):                                # creating needs the metadata (fl.pyx:327-334)
+        with pytest.raises(ValueError):
+            fl.open(name=str(tmp_path / "nometa.gsd"), mode=mode)
