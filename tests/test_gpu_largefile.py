@@ -22,7 +22,7 @@ def _sha(path):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("N", [2 ** 27, 2 ** 29 + 1])
+@pytest.mark.parametrize("N", [2 ** 27, 2 ** 29 + 1, 2 ** 30 + 3])     # 512 MiB, 2 GiB + 4 B, 4 GiB + 12 B
 def test_large_n(N):
     import torch
     gc.collect()
