@@ -24,7 +24,7 @@ def asan_driver():
 @pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("name,P", [("sph_full", 4), ("index_expand", 2), ("names_reloc", 5), ("maxbuf", 4),
                                     ("reopen", 2), ("midflush", 3), ("zero_rank", 8), ("alltypes", 1),
-                                    ("defaultargs", 3), ("vone_append", 2)])
+                                    ("defaultargs", 3), ("vone_append", 2), ("idxbuf", 3)])
 def test_scenarios_are_sanitizer_clean(asan_driver, name, P, batched, tmp_path):
     out = str(tmp_path / "out.gsd")
     script = S.scenario_path(name)
