@@ -18,13 +18,15 @@ declare -A RANKS=(
   [posvelid]="1 2 4 8" [sph_full]="1 2 4 8" [index_expand]="1 2 4 8"
   [zero_rank]="1 2 4 8" [alltypes]="1 3" [names_reloc]="1 2 5" [maxbuf]="1 2 4"
   [reopen]="1 2 4" [midflush]="1 2 3" [benchlike]="1 2 4 8"
-  [defaultargs]="1 2 3 4" [readback]="1 2 4" [vone_append]="1 2 3" [idxbuf]="1 2 3"
+  [defaultargs]="1 2 3 4" [readback]="1 2 4" [vone_append]="1 2 3" [idxbuf]="1 2 3" [errors]="1"
 )
 for scn in tests/golden/scenarios/*.scn; do
   name=$(basename "$scn" .scn)
   for p in ${RANKS[$name]}; do
     rm -f /tmp/golden_$$.gsd
-    timeout 120 $MPIEXEC -n "$p" oracle/_ref/ref_driver "$scn" /tmp/golden_$$.gsd > "$OUT/$name.p$p.log"
+    # errors.scn makes calls that fail on purpose: the driver then exits with 1 after finishing the script
+    timeout 120 $MPIEXEC -n "$p" oracle/_ref/ref_driver "$scn" /tmp/golden_$$.gsd > "$OUT/$name.p$p.log" \
+      || [ "$name" = errors ]
     mv /tmp/golden_$$.gsd "$OUT/$name.p$p.gsd"
   done
 done
