@@ -27,6 +27,8 @@ torch = pytest.importorskip("torch")
 
 INTS = ["uint8", "uint16", "uint32", "uint64", "int8", "int16", "int32", "int64"]
 FLOATS = ["float32", "float64"]
+import os
+N_SEEDS = int(os.environ.get("PGSD_FUZZ_SEEDS", "32"))     # a one-off wider campaign: PGSD_FUZZ_SEEDS=1000
 SIZES = [1, 2, 15, 16, 17, 63, 64, 65, 255, 1000, 1023, 1024, 1025, 2049, 4097, 10_007]
 
 
@@ -45,7 +47,7 @@ def out_types(sdt, rng):
     return ok
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_fused_pack(seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.choice(SIZES))
@@ -94,7 +96,7 @@ def test_random_fused_pack(seed):
         assert out.cpu().numpy().tobytes() == exp.tobytes(), (seed, i, N)
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_fused_unpack(seed):
     """chunks -> destination arrays; several chunks may share an array (disjoint columns), some
     arrays end up completely restored (row assembly), others keep untouched columns."""
