@@ -15,7 +15,9 @@
 // ncclAllGather over xGMI: the path a C++ caller (HOOMD-SPH's dump writer) takes without MPI or torch.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk] [shm|rccl]
+// With "keep" as 6th argument the file is left behind (benchmark_read.hip reads it back and checks the values).
+//
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk] [shm|rccl] [keep]
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -55,6 +57,7 @@ int main(int argc, char** argv)
     const int frames = argc > 2 ? atoi(argv[2]) : 10;
     const char* path = argc > 3 ? argv[3] : "/dev/shm/pgsd_benchmark_write.gsd";
     const bool batched = !(argc > 4 && strcmp(argv[4], "perchunk") == 0);
+    const bool keep = argc > 6 && strcmp(argv[6], "keep") == 0;
     CHECK(pgsd_comm_init_from_env());
     const int rank = pgsd_comm_rank(), P = pgsd_comm_size();
     int ndev = 0;
@@ -137,7 +140,8 @@ int main(int argc, char** argv)
                P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
                (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes,
                batched ? "one per frame" : "one per chunk", collectives, comm_name);
-        unlink(path);
+        if (!keep)
+            unlink(path);
         }
     pgsd_comm_finalize();
     (void)hipFree(pos);

@@ -54,3 +54,34 @@ def test_two_ranks_share_the_gpu_one_exchange_per_frame(tmp_path):
     # allgather for its report and its timing barriers go through the default communicator, not the handle;
     # the barrier pgsd_close makes up comes after the count was read)
     assert d["collectives_rank0"] == 2 + 5, d
+
+
+READ_EXE = os.path.join(product.CSRC, "build", "benchmark_read")
+
+
+def _run_ranks(exe, args, P, timeout=300):
+    shm = "pgsdnative_%s" % uuid.uuid4().hex[:10]
+    procs = [subprocess.Popen([exe] + [str(a) for a in args],
+                              env=dict(os.environ, PGSD_RANK=str(r), PGSD_NRANKS=str(P), PGSD_SHM_NAME=shm),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(P)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (o[-500:], e[-1500:])
+    return json.loads(outs[0][0].strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("writers,readers", [(1, 1), (2, 3), (3, 2)])
+def test_read_harness_restores_what_the_write_harness_wrote(tmp_path, writers, readers):
+    """benchmark_read.hip (the counterpart of scripts/benchmark-read.cc): every rank reads an even share of the rows
+    of every frame straight into Scalar4 arrays in HBM and a kernel compares them with the closed-form values the
+    write harness produced -- whatever partition wrote the file."""
+    product.build()
+    path = str(tmp_path / "native.gsd")
+    per_rank, frames = 100003, 3
+    d = _run_ranks(EXE, [per_rank, frames, path, "batched", "shm", "keep"], writers)
+    assert d["ranks"] == writers and os.path.exists(path)
+    r = _run_ranks(READ_EXE, [path, "verify"], readers)
+    n_global = per_rank * writers
+    assert r["ranks"] == readers and r["frames"] == frames + 1 and r["particles"] == n_global
+    assert r["verified"] is True and r["mismatches"] == 0
+    assert r["rows_read"] == (frames + 1) * n_global and r["bytes_read"] == (frames + 1) * n_global * 28
