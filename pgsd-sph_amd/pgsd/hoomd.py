@@ -283,6 +283,7 @@ class HOOMDTrajectory(object):
             raise ValueError('Append mode not yet supported')
         self._file = file
         self._initial_frame = None
+        self._device_defaults = {}
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
             raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
@@ -290,6 +291,11 @@ class HOOMDTrajectory(object):
         if not (version < (2, 0) and version >= (1, 0)):
             raise RuntimeError('Incompatible hoomd schema version ' + str(version) + ' in: ' + str(self.file))
         logger.info('found ' + str(len(self)) + ' frames')
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_device_defaults'] = {}       # cached one-row default tensors in HBM: rebuilt on demand
+        return state
 
     @property
     def file(self):
@@ -658,16 +664,27 @@ class HOOMDTrajectory(object):
         snap.part = (row0, n)
 
         specs = list(_PARTICLE_SPEC.items()) + list(_PARTICLE_SPEC_EXTRA.items())
+        n_frame0 = None          # frame 0's arrays stand in only while the particle count is frame 0's (hoomd.py:858-884)
         for name, (dt, M) in specs:
             chunk = 'particles/' + name
             fr = frame_of(chunk)
-            if fr is not None and int(f.read_chunk(fr, 'particles/N')[0] if f.chunk_exists(fr, 'particles/N') else n_global) == n_global:
+            if fr == 0 and idx != 0:
+                if n_frame0 is None:
+                    n_frame0 = int(f.read_chunk(0, 'particles/N')[0]) if f.chunk_exists(0, 'particles/N') else n_global
+                if n_frame0 != n_global:
+                    fr = None
+            if fr is not None:
                 setattr(snap.particles, name, f.read_chunk_device(fr, chunk, N=n, offset=row0, wait=False))
             elif name in snap.particles._default_value:
-                default = numpy.asarray(snap.particles._default_value[name])
-                t = torch.empty((n, M) if M > 1 else (n,), dtype=getattr(torch, numpy.dtype(dt).name), device='cuda')
-                t[...] = torch.as_tensor(default.astype(dt)).to(t.device)
-                setattr(snap.particles, name, t)
+                # like the host reader (hoomd.py:872-881) a default is ONE row broadcast over the particles: no
+                # allocation, no copy; `.contiguous()` / `.clone()` gives an array of its own
+                key = (name, torch.cuda.current_device())
+                row = self._device_defaults.get(key)
+                if row is None:
+                    default = numpy.broadcast_to(numpy.asarray(snap.particles._default_value[name], dtype=dt), (M,))
+                    row = torch.as_tensor(numpy.array(default)).to('cuda')      # (a writable copy: torch refuses read-only views)
+                    self._device_defaults[key] = row
+                setattr(snap.particles, name, row.expand(n, M) if M > 1 else row.expand(n))
         if scalar4 and n >= 0:
             pos4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
             vel4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')

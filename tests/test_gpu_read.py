@@ -279,6 +279,15 @@ def test_hoomd_read_frame_device_round_trip(tmp_gsd):
         assert torch.equal(s.particles.position, pos4[:, :3].contiguous())
         assert torch.equal(s.particles.typeid.view(torch.int32), tid)
         assert float(s.particles.density.abs().sum()) == 0.0          # default
+        # fields no frame holds are ONE default row broadcast over the particles (the host reader's read-only
+        # broadcast arrays, hoomd.py:872-881): right shape and dtype, no storage of their own until asked for
+        body, image = s.particles.body, s.particles.image
+        assert body.shape == (N,) and body.dtype == torch.int32 and body.stride(0) == 0
+        assert image.shape == (N, 3) and image.dtype == torch.int32 and image.stride(0) == 0
+        assert bool((body == -1).all()) and bool((image == 0).all()) and bool((s.particles.slength == 1).all())
+        own = body.contiguous()
+        own[0] = 7
+        assert int(own[0]) == 7 and int(body[0]) == -1
         part = t.read_frame_device(0, part=(100, 777))
         assert part.particles.N == 777
         assert torch.equal(part.particles.velocity, vel4[100:877, :3].contiguous())
