@@ -264,6 +264,25 @@ class _FrameSubset(object):
         return self._trajectory[picked]
 
 
+def _equal(a, b):
+    """`numpy.array_equal`, deciding from the first rows where it can: a 10^6-particle array that differs from
+    frame 0 differs in its first rows, and comparing all of it costs as much as writing it."""
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.ndim >= 1 and a.shape[0] > 4096 and not numpy.array_equal(a[:1024], b[:1024]):
+        return False
+    return bool(numpy.array_equal(a, b))
+
+
+def _equiv(a, default):
+    """`numpy.array_equiv(a, default)` (default broadcast over the rows), first rows first."""
+    a = numpy.asarray(a)
+    if a.ndim >= 1 and a.shape[0] > 4096 and not numpy.array_equiv(a[:1024], default):
+        return False
+    return bool(numpy.array_equiv(a, default))
+
+
 def _encode_strings(strings):
     """list[str] -> (n, wid) int8 array, NUL padded (hoomd.py:628-630)."""
     wid = max(len(w.encode('utf-8')) for w in strings) + 1
@@ -469,7 +488,7 @@ class HOOMDTrajectory(object):
         if self._initial_frame is not None:
             initial_container = getattr(self._initial_frame, path)
             initial_data = getattr(initial_container, name, None)
-            if initial_data is not None and numpy.array_equal(initial_data, data):
+            if initial_data is not None and _equal(initial_data, data):
                 logger.debug('skipping data chunk, matches frame 0: ' + path + '/' + name)
                 return False
         default = container._default_value.get(name)
@@ -478,7 +497,7 @@ class HOOMDTrajectory(object):
         if name in ('types', 'type_shapes'):
             matches_default_value = data == default
         else:
-            matches_default_value = numpy.array_equiv(data, default)
+            matches_default_value = _equiv(data, default)
         if matches_default_value and not self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
             logger.debug('skipping data chunk, default value: ' + path + '/' + name)
             return False
