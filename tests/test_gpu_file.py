@@ -196,6 +196,13 @@ def test_multi_rank_device_write_matches_oracle(counts, async_seal, batched, tmp
         assert a.read() == b.read()
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_five_ranks_share_the_gpu(batched, tmp_path):
+    """as many ranks as the box lets use the card next to the test process itself (6 processes in all): uneven
+    partition with an empty and a one-row rank"""
+    test_multi_rank_device_write_matches_oracle([5000, 0, 1, 77, 4096], False, batched, tmp_path)
+
+
 def test_hoomd_append_with_device_fields(tmp_path):
     """pgsd.hoomd.HOOMDTrajectory.append with GPU-resident attributes (one fused launch) equals
     the same trajectory written from host copies."""
