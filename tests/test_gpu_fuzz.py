@@ -30,6 +30,8 @@ FLOATS = ["float32", "float64"]
 import os
 N_SEEDS = int(os.environ.get("PGSD_FUZZ_SEEDS", "32"))     # a one-off wider campaign: PGSD_FUZZ_SEEDS=1000
 SIZES = [1, 2, 15, 16, 17, 63, 64, 65, 255, 1000, 1023, 1024, 1025, 2049, 4097, 10_007]
+if os.environ.get("PGSD_FUZZ_BIG"):       # one-off campaign around the launch-geometry switches (2^21 rows) and odd tails
+    SIZES = [262_143, 524_289, 1_000_003, 2_097_151, 2_097_152, 2_097_153, 2_500_001]
 
 
 def dev_bytes(a):
