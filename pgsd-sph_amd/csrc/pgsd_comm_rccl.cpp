@@ -43,11 +43,23 @@ static bool load_rccl()
         return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
+    // PGSD_RCCL_LIBRARY: a particular RCCL build (or the tests' stand-in, tests/drivers/fake_rccl.cpp); its symbols
+    // stay local, everything is reached through dlsym on the handle
+    const char* chosen = getenv("PGSD_RCCL_LIBRARY");
+    if (chosen && *chosen)
+        {
+        lib = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        if (!lib)
+            {
+            set_last_error(std::string("cannot load PGSD_RCCL_LIBRARY: ") + dlerror());
+            return false;
+            }
+        }
     for (const char* n : names)
         {
-        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (lib)
             break;
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
     if (!lib)
         {

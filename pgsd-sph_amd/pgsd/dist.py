@@ -10,6 +10,7 @@ pgsd.c:106-202) from a ``torch.distributed`` process group.
 * A single process needs nothing: the default communicator is "self".
 """
 import ctypes
+import os
 
 import numpy
 
@@ -54,10 +55,14 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
         init_self()
         return "self"
     backend = dist.get_backend(group)
-    if prefer_rccl and backend == "nccl" and torch.cuda.is_available():
+    # PGSD_RCCL_LIBRARY names a particular RCCL build -- or the tests' stand-in, which lets ranks that SHARE a GPU
+    # (a gloo group on a one-GPU box) go through the native back end's code; the name then shows in the result
+    chosen = os.environ.get("PGSD_RCCL_LIBRARY", "")
+    if prefer_rccl and torch.cuda.is_available() and (backend == "nccl" or chosen):
         if device is None:
             device = torch.cuda.current_device()
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % device)
+        where = "cuda:%d" % device if backend == "nccl" else "cpu"    # where the group's own collectives run
+        uid = torch.zeros(128, dtype=torch.uint8, device=where)
         if rank == 0:
             buf = (ctypes.c_uint8 * 128)()
             if lib.pgsd_comm_rccl_unique_id(buf) == 0:
@@ -77,12 +82,12 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
                 err = "rccl self-check allgather returned %r: %s" % (list(got), _lib.last_error())
                 rc = rc or -1
         # every rank takes the same decision, or the ranks would sit on different communicators
-        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda:%d" % device)
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 0:
             lib.pgsd_comm_finalize()
             raise RuntimeError("pgsd_comm_init_rccl failed on at least one rank: " + (err or "(another rank)"))
-        return "rccl"
+        return "rccl" if not chosen else "rccl[%s]" % os.path.basename(chosen)
 
     on_gpu = backend == "nccl"
 
