@@ -61,3 +61,20 @@ def test_device_write_without_gpu_raises(tmp_gsd):
         field = fl.DeviceField(ptr=0x1000, dtype=np.float32, N=8, M=3, stride=4)
         with pytest.raises(RuntimeError, match="no HIP device"):
             f.write_chunk('particles/position', field)
+
+
+def test_rccl_library_override_is_honoured_and_fails_loudly():
+    """PGSD_RCCL_LIBRARY names the RCCL build the communicator loads; a path that cannot be loaded is an error of
+    the call (no silent fall-back to another librccl).  No GPU needed: the id call only opens the library."""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes; sys.path.insert(0, %r)\n"
+            "from pgsd import _lib\n"
+            "buf = (ctypes.c_uint8 * 128)()\n"
+            "rc = _lib.lib.pgsd_comm_rccl_unique_id(buf)\n"
+            "print(rc, _lib.last_error())\n" % os.path.join(product.ROOT, "pgsd-sph_amd"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PGSD_RCCL_LIBRARY="/nonexistent/librccl.so"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    rc, msg = p.stdout.strip().split(" ", 1)
+    assert int(rc) != 0 and "PGSD_RCCL_LIBRARY" in msg and "/nonexistent/librccl.so" in msg
