@@ -45,3 +45,41 @@ def test_scenarios_are_sanitizer_clean(asan_driver, name, P, batched, tmp_path):
         assert rc == 0 and "ERROR" not in err and "runtime error" not in err, err[-2000:]
     with open(out, "rb") as a, open(os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P)), "rb") as b:
         assert a.read() == b.read()
+
+
+TSAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_tsan")
+
+BIG_CHUNKS = """create app hoomd 1 4 rw 0
+seed 5
+chunk configuration/step u64 1 0 same:1
+chunk particles/position f32 3 1 even:7000000
+chunk particles/velocity f32 3 1 even:7000000
+end_frame
+chunk configuration/step u64 1 0 same:1
+chunk particles/position f32 3 1 even:7000000
+end_frame
+dump
+read 0 particles/position 7000000 3 0 0 7000000 3 4
+read 1 particles/position 3000000 3 1000 1 3000000 3 4
+close
+"""
+
+
+def test_writer_pool_and_read_threads_are_race_free(tmp_path):
+    """ThreadSanitizer over the threads the host layer starts inside one process: 84 MB chunks are split over the
+    writer pool on the way out and over the host read threads on the way in.  The file must equal the oracle's."""
+    r = subprocess.run(["make", "-C", product.CSRC, "tsan"], capture_output=True)
+    if r.returncode != 0 or not os.path.exists(TSAN_DRIVER):
+        pytest.skip("sanitizer build not available: " + r.stderr.decode()[-300:])
+    scn = tmp_path / "big.scn"
+    scn.write_text(BIG_CHUNKS)
+    out, ref = str(tmp_path / "out.gsd"), str(tmp_path / "ref.gsd")
+    p = subprocess.run([TSAN_DRIVER, str(scn), out], env=dict(os.environ, PGSD_RANK="0", PGSD_NRANKS="1"),
+                       capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in p.stderr and "unexpected memory mapping" in p.stderr:
+        pytest.skip("ThreadSanitizer cannot run in this container")
+    assert p.returncode == 0 and "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
+    log = S.run_oracle(str(scn), ref, 1)
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == log
+    with open(out, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read()
