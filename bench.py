@@ -403,9 +403,13 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%d particles/GPU, position+velocity+typeid packed from %s, "
+        "config": {"workload": "%d particles/GPU, %s packed from %s, "
                                "%s allgather of chunk sizes (one per frame), one shared GSD file on %s"
-                               % (N, layout, comm_backend, args.dir),
+                               % (N, {"pvi": "position+velocity+typeid",
+                                      "sph": "the 14 per-particle chunks of the PGSD-SPH schema (112 B/particle)",
+                                      "union": "the 19 per-particle chunks of the SPH schema + upstream HOOMD attributes "
+                                               "(164 B/particle)"}[args.schema], layout, comm_backend, args.dir),
+                   "schema": args.schema,
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
         "comm_backend": comm_backend,
