@@ -32,6 +32,9 @@ def make_script(seed, P):
     if rng.random() < 0.35:
         maxbuf = rng.choice([48, 64, 200, 1024, 4096])
         lines.append("maxbuf %d" % maxbuf)
+    rng_idx = random.Random(seed * 7919 + 13)      # a stream of its own: the scripts of earlier rounds keep their lines
+    if rng_idx.random() < 0.3:
+        lines.append("idxbuf %d" % rng_idx.choice([1, 2, 5, 20]))   # end_frame leaves buffered-only frames unflushed
     names = rng.sample(NAMES, rng.randint(3, len(NAMES)))
     n_frames = rng.randint(2, 14)
     cur, last_nonempty = 0, -1      # the file's frame counter: a re-open continues behind the last frame that has entries
@@ -124,6 +127,8 @@ def make_script(seed, P):
             if rng.random() < 0.5:
                 maxbuf = rng.choice([64, 4096])
                 lines.append("maxbuf %d" % maxbuf)
+            if rng_idx.random() < 0.3:
+                lines.append("idxbuf %d" % rng_idx.choice([1, 3, 50]))
     lines += ["dump", "close", "open ro", "dump", "names", "find 0 %s" % names[0], "close"]
     return "\n".join(lines) + "\n"
 
