@@ -227,7 +227,11 @@ extern "C"
        was opened: the evidence behind "one collective per frame" (bench.py, tests). */
     uint64_t pgsd_get_collective_count(struct pgsd_handle* handle);
 
-    /* reference pgsd.h:581-582 */
+    /* reference pgsd.h:581-582.  The reference flushes first (collective).  Here the index is replicated:
+       the call flushes (collectively) only while written chunks / names / index entries are still pending --
+       replicated state, every rank decides alike -- and is LOCAL otherwise, so a lookup made by one rank
+       only (after pgsd_end_frame) cannot strand the other ranks in a collective.  Same for
+       pgsd_find_matching_chunk_name. */
     const struct pgsd_index_entry*
     pgsd_find_chunk(struct pgsd_handle* handle, uint64_t frame, const char* name);
 

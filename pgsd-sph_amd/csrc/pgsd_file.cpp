@@ -748,6 +748,44 @@ static int do_flush(Impl* s, bool async = false, bool sync_point = true)
     return arc != PGSD_SUCCESS ? arc : qrc;
     }
 
+// What a LOOKUP (pgsd_find_chunk, pgsd_find_matching_chunk_name) needs from the flush the reference runs
+// first (pgsd.c:2316, 2586): the replicated index and name list must hold everything written so far.  Whether
+// they do is a matter of replicated state, so every rank decides alike.  When they do, nothing is left but
+// the barrier a batched frame still owes (`unsynced`) or this rank's own asynchronous copies (`inflight`),
+// neither of which a lookup needs: it stays LOCAL then -- a caller may look chunks up on one rank only
+// (HOOMDTrajectory._should_write did, from its third frame on: ADVICE r2) without leaving the others
+// outside a collective.  Reads still flush in full: they need the other ranks' bytes in the file.
+static bool metadata_pending(const Impl* s)
+    {
+    bool work = !s->queue.empty() || s->frame_n_names > 0 || !s->buffer_index.empty() || !s->frame_index.empty()
+                || s->dirty_data;
+    for (uint64_t b : s->wb_sizes)
+        work = work || b > 0;
+    return work;
+    }
+
+static int flush_for_lookup(Impl* s)
+    {
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_SUCCESS;
+    if (metadata_pending(s))
+        return do_flush(s);
+    if (s->dev && s->inflight)
+        {
+        // local: this rank's rows of the asynchronously sealed frames reach the file (documented in pgsd.h)
+        s->inflight = false;
+        std::string err;
+        const int drc = device_pipeline_drain(s->dev, &err);
+        if (drc != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            remember_failure(s, drc, drc == PGSD_ERROR_IO ? errno : 0); // every rank hears of it at the next flush
+            return drc;
+            }
+        }
+    return PGSD_SUCCESS;
+    }
+
 static int do_end_frame(Impl* s, bool async = false)
     {
     // pgsd.c:1916-1953
@@ -1462,7 +1500,7 @@ extern "C" const struct pgsd_index_entry* pgsd_find_chunk(struct pgsd_handle* ha
         return NULL;
     if (s->flags != PGSD_OPEN_READONLY)
         {
-        int rc = do_flush(s);
+        int rc = flush_for_lookup(s);
         publish(handle, s);
         if (rc != PGSD_SUCCESS)
             return NULL;
@@ -1578,7 +1616,7 @@ extern "C" const char* pgsd_find_matching_chunk_name(struct pgsd_handle* handle,
                 return NULL;
             prev_off = (size_t)(prev - s->file_names.d.data());
             }
-        int rc = do_flush(s);
+        int rc = flush_for_lookup(s);
         publish(handle, s);
         if (rc != PGSD_SUCCESS)
             return NULL;

@@ -302,7 +302,7 @@ class HOOMDTrajectory(object):
             raise ValueError('Append mode not yet supported')
         self._file = file
         self._initial_frame = None
-        self._device_defaults = {}
+        self._frame0_chunks = None
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
             raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
@@ -310,11 +310,6 @@ class HOOMDTrajectory(object):
         if not (version < (2, 0) and version >= (1, 0)):
             raise RuntimeError('Incompatible hoomd schema version ' + str(version) + ' in: ' + str(self.file))
         logger.info('found ' + str(len(self)) + ' frames')
-
-    def __getstate__(self):
-        state = dict(self.__dict__)
-        state['_device_defaults'] = {}       # cached one-row default tensors in HBM: rebuilt on demand
-        return state
 
     @property
     def file(self):
@@ -371,6 +366,19 @@ class HOOMDTrajectory(object):
         # the initial frame is the reference for elision
         if self._initial_frame is None and len(self) > 0:
             self._read_frame(0)
+        # ... and so is the set of chunks frame 0 holds (hoomd.py:689-691).  Looked up ONCE, by every rank, for
+        # every name in the same order -- never from inside a comparison only some ranks make: a lookup flushes
+        # whatever is pending, which is collective (a rank whose velocities are all zero would ask alone)
+        if self._frame0_chunks is None and len(self) > 0:
+            self._frame0_chunks = set()
+            for path in ('configuration', 'particles', 'constraints'):
+                container = getattr(frame, path)
+                names = list(container._default_value)
+                if path == 'particles':
+                    names += list(container._extra_default_value)
+                for name in names:
+                    if self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
+                        self._frame0_chunks.add(path + '/' + name)
 
         # From here on the frame costs two collectives however many chunks it has: the allgather below
         # (row counts + write/skip votes) and the one frame exchange of end_frame, which places every
@@ -498,7 +506,7 @@ class HOOMDTrajectory(object):
             matches_default_value = data == default
         else:
             matches_default_value = _equiv(data, default)
-        if matches_default_value and not self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
+        if matches_default_value and (path + '/' + name) not in (self._frame0_chunks or ()):
             logger.debug('skipping data chunk, default value: ' + path + '/' + name)
             return False
         return True
@@ -696,13 +704,11 @@ class HOOMDTrajectory(object):
                 setattr(snap.particles, name, f.read_chunk_device(fr, chunk, N=n, offset=row0, wait=False))
             elif name in snap.particles._default_value:
                 # like the host reader (hoomd.py:872-881) a default is ONE row broadcast over the particles: no
-                # allocation, no copy; `.contiguous()` / `.clone()` gives an array of its own
-                key = (name, torch.cuda.current_device())
-                row = self._device_defaults.get(key)
-                if row is None:
-                    default = numpy.broadcast_to(numpy.asarray(snap.particles._default_value[name], dtype=dt), (M,))
-                    row = torch.as_tensor(numpy.array(default)).to('cuda')      # (a writable copy: torch refuses read-only views)
-                    self._device_defaults[key] = row
+                # N-row allocation, no copy; `.contiguous()` / `.clone()` gives an array of its own.  The reference
+                # marks its defaults read-only; torch has no such flag, so the row is built afresh for every
+                # read: a write through the view changes this frame's view only, never a later frame's default
+                default = numpy.broadcast_to(numpy.asarray(snap.particles._default_value[name], dtype=dt), (M,))
+                row = torch.as_tensor(numpy.array(default)).to('cuda')      # (a writable copy: torch refuses read-only views)
                 setattr(snap.particles, name, row.expand(n, M) if M > 1 else row.expand(n))
         if scalar4 and n >= 0:
             pos4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')

@@ -60,6 +60,25 @@ def _worker(rank, world, port, path, counts, mode):
             f.write_chunk('particles/position', S.gen_data(9, 90 + frame, row0, n, 3), offset=got_counts, rank=rank)
             f.end_frame()
         f.close()
+    elif mode == "hoomd_default_rank":
+        # one rank's host data equals the DEFAULT value (zero velocity, typeid 0), the other rank's does not,
+        # over more frames than it takes for a batched seal to be pending: the elision
+        # test's frame-0 lookup must not be a collective that only some ranks enter
+        t = hoomd.open(path, 'w')
+        for frame in range(5):
+            seed = 160 + frame
+            fr = hoomd.Frame()
+            fr.configuration.step = frame
+            fr.particles.N = n
+            fr.particles.position = S.gen_data(9, seed, row0, n, 3)
+            if rank == 0:
+                fr.particles.velocity = np.zeros((n, 3), dtype=np.float32)
+                fr.particles.typeid = np.zeros(n, dtype=np.uint32)
+            else:
+                fr.particles.velocity = S.gen_data(9, seed + 100, row0, n, 3)
+                fr.particles.typeid = S.gen_data(3, seed, row0, n, 1)[:, 0] % 3 + 1
+            t.append(fr)
+        t.close()
     else:
         t = hoomd.open(path, 'w')
         for frame in range(2):
@@ -178,3 +197,30 @@ def test_hoomd_append_two_ranks(tmp_path):
             dens = S.gen_data(9, seed + 200, 0, 9, 1)[:, 0]
             np.testing.assert_array_equal(s.particles.density[:6], dens[:6])
             np.testing.assert_array_equal(s.particles.density[6:], np.zeros(3, dtype=np.float32))
+
+
+@pytest.mark.parametrize("counts", [[6, 3], [4, 0, 5]])
+def test_hoomd_append_rank_with_default_valued_fields(counts, tmp_path):
+    """A rank whose slice is all-default (zero velocity, typeid 0, or no particles at all) next to a rank
+    whose slice is not, over five frames: from the third append on round 2's `_should_write` issued a
+    collective (the flush inside `chunk_exists`) on the all-default rank only -- PGSD_ERROR_COMM over shm and
+    gloo, a hang over RCCL / MPI."""
+    P = len(counts)
+    mine = str(tmp_path / "traj.gsd")
+    tmp_mp.spawn(_worker, args=(P, free_port(), mine, counts, "hoomd_default_rank"), nprocs=P, join=True)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgsd-sph_amd"))
+    import pgsd.hoomd as hoomd
+    Ng, n0 = sum(counts), counts[0]
+    with hoomd.open(mine, 'r') as t:
+        assert len(t) == 5
+        for frame in range(5):
+            seed = 160 + frame
+            s = t[frame]
+            assert s.particles.N == Ng and s.configuration.step == frame
+            np.testing.assert_array_equal(s.particles.position, S.gen_data(9, seed, 0, Ng, 3))
+            vel = S.gen_data(9, seed + 100, 0, Ng, 3)
+            vel[:n0] = 0
+            np.testing.assert_array_equal(s.particles.velocity, vel)
+            tid = S.gen_data(3, seed, 0, Ng, 1)[:, 0] % 3 + 1
+            tid[:n0] = 0
+            np.testing.assert_array_equal(s.particles.typeid, tid)
