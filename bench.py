@@ -9,10 +9,15 @@ into one shared GSD file on tmpfs, index commit (pgsd_end_frame).
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches it with torch.distributed.run (one rank per GPU); ranks share
-ONE output file, each writing its own partition (weak scaling: 10 M particles per GPU).
+N > 1: one rank per GPU; the ranks share ONE output file, each writing its own partition (weak
+scaling: 10 M particles per GPU).  Either the driver launches the ranks (torch.distributed.run:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, and WORLD_SIZE must equal --gpus), or
+-- WORLD_SIZE unset -- this script starts them itself: the parent process spawns N rank children
+BEFORE anything touches torch or the GPU, relays rank 0's JSON line and exits with their status
+(the reference's harness finds its ranks the same way inside the program, benchmark-write.cc:24-45).
 Rank 0 prints one JSON line (contract in the task description) with `roofline` for the pack
-kernel and `cpu_baseline` for the CPU restatement of the reference path (oracle/, N=1 only).
+kernel, `exchange_us` for the frame's one allgather and `cpu_baseline` for the reference's CPU
+path on the host's cores (P ranks for N = P GPUs; `nproc` stated).
 """
 import argparse
 import ctypes
@@ -30,32 +35,39 @@ ALGO_BYTES_PER_PARTICLE = 56   # read pos.xyz + vel.xyz + typeid (28 B) + write 
 PAYLOAD_BYTES_PER_PARTICLE = 28
 
 
-def cpu_baseline_reference(n_particles, frames, out_dir):
+def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1):
     """Time the reference ITSELF (oracle/_ref/ref_bench = the reference's pgsd.c compiled in the
-    build container + tests/drivers/ref_bench.c) under MPICH on this host: one rank = one core,
-    plus a 4-rank run of the same total workload for orientation.  None when it cannot run."""
+    build container + tests/drivers/ref_bench.c) under MPICH on this host's cores: `ranks` MPI ranks
+    (one core each, one per GPU of the run, as SURVEY 8(d) prescribes) writing `n_particles` each,
+    plus a second run on more ranks (min(4 * ranks, nproc)) of the same total workload to show what
+    more cores buy.  None when it cannot run."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     mpiexec = "/opt/conda/bin/mpiexec"
     if not (os.path.exists(exe) and os.path.exists(mpiexec)):
         return None
+    nproc = os.cpu_count() or 1
+    more = min(4 * ranks, nproc)
     path = os.path.join(out_dir, "pgsd_bench_ref_%d.gsd" % os.getpid())
     res = {}
     try:
-        for ranks in (1, 4):
-            out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(n_particles), str(frames), path],
+        for r in sorted({ranks, more}):
+            out = subprocess.run([mpiexec, "-n", str(r), exe, str(n_particles * ranks), str(frames), path],
                                  capture_output=True, timeout=300, check=True).stdout.decode()
-            res[ranks] = json.loads(out.strip().splitlines()[-1])
+            res[r] = json.loads(out.strip().splitlines()[-1])
     except Exception as e:  # missing MPI runtime, time-out, ...
         print("bench.py: reference baseline unavailable (%s), using the oracle port" % e, file=sys.stderr)
         return None
     finally:
         if os.path.exists(path):
             os.unlink(path)
-    return {"value": round(res[1]["GBps"], 4), "unit": "GB/s", "cores": 1, "kind": "reference",
-            "sample": "%d frames x %d particles (pos+vel+typeid): C pack loop out of float4 arrays + the "
-                      "reference's pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), 1 rank on 1 core, file "
-                      "on %s; the same workload on 4 ranks: %.3f GB/s" % (frames, n_particles, out_dir, res[4]["GBps"])}
+    return {"value": round(res[ranks]["GBps"], 4), "unit": "GB/s", "cores": ranks, "kind": "reference",
+            "nproc": nproc, "ranks": ranks,
+            "more_cores": {"ranks": more, "value": round(res[more]["GBps"], 4)},
+            "sample": "%d frames x %d particles per rank (pos+vel+typeid): C pack loop out of float4 arrays + the "
+                      "reference's pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), %d rank(s) = %d core(s) of %d, "
+                      "one shared file on %s; the same total workload on %d ranks: %.3f GB/s"
+                      % (frames, n_particles, ranks, ranks, nproc, out_dir, more, res[more]["GBps"])}
 
 
 def cpu_baseline(n_particles, frames, out_dir):
@@ -95,7 +107,7 @@ def cpu_baseline(n_particles, frames, out_dir):
     lib.oracle_close(h)
     os.unlink(path)
     gbs = frames * n_particles * PAYLOAD_BYTES_PER_PARTICLE / dt / 1e9
-    return {"value": round(gbs, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+    return {"value": round(gbs, 4), "unit": "GB/s", "cores": 1, "kind": "port", "nproc": os.cpu_count() or 1, "ranks": 1,
             "sample": "%d frames x %d particles (pos+vel+typeid), float4 -> chunk pack in C + "
                       "reference write sequence, 1 thread, file on %s" % (frames, n_particles, out_dir)}
 
@@ -147,7 +159,7 @@ def pmc_pass(counter, child_args, timeout):
 def measure_traffic_live(args):
     """-> (HBM bytes per frame's pack launch(es), source text, detail) from two PMC passes, or Nones."""
     child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--particles", str(args.particles), "--schema", args.schema,
-             "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test"]
+             "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test", "--no-exchange-probe"]
     if args.separate_id:
         child.append("--separate-id")
     fetch = pmc_pass("FETCH_SIZE", child, 240)
@@ -180,6 +192,70 @@ def traffic_from_file(N, args):
     return None, None
 
 
+def probe_rccl_exchange(device, n=300, nbytes=512):
+    """Median / p99 wall time (us) of the library's allgather on a ONE-rank RCCL communicator, or None."""
+    try:
+        from pgsd import _lib
+        lib = _lib.lib
+        uid = (ctypes.c_uint8 * 128)()
+        if lib.pgsd_comm_rccl_unique_id(uid) != 0 or lib.pgsd_comm_init_rccl(uid, 0, 1, int(device)) != 0:
+            print("bench.py: no RCCL exchange probe (%s)" % _lib.last_error(), file=sys.stderr)
+            return None
+        send = (ctypes.c_uint8 * nbytes)()
+        recv = (ctypes.c_uint8 * nbytes)()
+        times = []
+        for i in range(n + 20):
+            t0 = time.perf_counter()
+            rc = lib.pgsd_comm_allgather(send, recv, nbytes)
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                lib.pgsd_comm_finalize()
+                return None
+            if i >= 20:
+                times.append(dt * 1e6)
+        lib.pgsd_comm_finalize()
+        times.sort()
+        return {"backend": "rccl, 1 rank (no xGMI hop)", "bytes": nbytes, "samples": n,
+                "median_us": round(times[len(times) // 2], 1), "p99_us": round(times[int(len(times) * 0.99) - 1], 1),
+                "min_us": round(times[0], 1)}
+    except Exception as e:  # measurement aside: never fails the run
+        print("bench.py: RCCL exchange probe failed (%s)" % e, file=sys.stderr)
+        return None
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank run: start N children of this script with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set (what torch.distributed.run would export), pass rank 0's stdout through and
+    return a non-zero status if any rank fails.  The parent never imports torch and never touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                # a rank that died leaves the others inside a collective: end them (exactly these children)
+                for q in pending:
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +265,8 @@ def main():
     ap.add_argument("--dir", default=os.environ.get("PGSD_BENCH_DIR", "/dev/shm"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stall-test", action="store_true", help="skip the asynchronous-sealing stall measurement")
+    ap.add_argument("--no-exchange-probe", action="store_true",
+                    help="N=1: skip timing one exchange on a one-rank RCCL communicator")
     ap.add_argument("--slab-mib", type=int, default=0)
     ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--writers", type=int, default=0)
@@ -207,18 +285,36 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    # --gpus N is the number of ranks of the run, always.  Ranks started by a launcher (WORLD_SIZE set) must
+    # be N of them; without a launcher and N > 1 this process becomes the launcher -- before torch or HIP are
+    # touched, so no GPU-initialised process ever starts or replaces another.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != args.gpus:
+            raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: the two must agree "
+                             "(the JSON's n_gpus is the number of ranks that ran)" % (world, args.gpus))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.rehearse_shared_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); one rank per GPU is the contract "
+                         "(--rehearse-shared-gpu lets the ranks share cuda:0 over a gloo group, for rehearsals only)"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     red_dev = "cuda"
     if world > 1:
@@ -328,6 +424,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     f.device_stats(reset=True)
+    f.exchange_stats(reset=True)
     fence()
     coll0 = f.collective_count
     t0 = time.perf_counter()
@@ -336,6 +433,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stats = f.device_stats()
+    xstats = f.exchange_stats()
     collectives_per_frame = (f.collective_count - coll0) / max(args.steps, 1)
 
     # What a simulation is blocked for per snapshot when it seals frames asynchronously: issue the
@@ -356,6 +454,8 @@ def main():
         stall_ms = round(min(stalls), 3)
     f.close()
 
+    exch_mean = xstats["total_us"] / max(xstats["count"], 1)
+    exchange_us = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -363,6 +463,14 @@ def main():
         pk = torch.tensor([stats["pack_ms"] / max(stats["pack_launches"], 1)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(pk, op=dist.ReduceOp.MAX)
         pack_ms = float(pk.item())
+        # the frame's one allgather as each rank's calling thread saw it (pgsd_get_exchange_stats): the mean
+        # of the slowest rank, the fastest rank's mean (the last to arrive waits least: closest to the
+        # transport's own latency) and the worst single exchange anywhere
+        xs = torch.tensor([exch_mean, -exch_mean, xstats["max_us"]], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(xs, op=dist.ReduceOp.MAX)
+        exchange_us = {"mean": round(float(xs[0]), 1), "mean_fastest_rank": round(-float(xs[1]), 1),
+                       "max": round(float(xs[2]), 1), "per_rank_count": xstats["count"], "bytes_per_rank": 512,
+                       "what": "wall time of the allgather call on the rank's thread: transport + wait for the slowest rank"}
     else:
         pack_ms = stats["pack_ms"] / max(stats["pack_launches"], 1)
     if rank == 0:
@@ -374,10 +482,16 @@ def main():
     if world > 1:
         dist.barrier()
         pdist.finalize()          # tears down the library's RCCL communicator on every rank
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
+
+    # N = 1 has no exchange (a single rank skips it).  What ONE 512-byte exchange costs on the RCCL back end is
+    # probed on a one-rank RCCL communicator instead: pinned -> device copy, ncclAllGather, device -> pinned copy,
+    # stream synchronize (pgsd_comm_rccl.cpp) -- the floor under the N > 1 figure, no xGMI hop in it.
+    exchange_probe = None
+    if world == 1 and not args.no_exchange_probe:
+        exchange_probe = probe_rccl_exchange(local_rank)
 
     # HBM bytes of one pack launch from the PMC counters (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and
     # WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950 for wide coalesced reads)
@@ -414,22 +528,26 @@ def main():
                    "parallelism": "particle-partition x%d" % world},
         "comm_backend": comm_backend,
         "collectives_per_frame": collectives_per_frame,
+        "exchange_us": exchange_us,
+        "exchange_probe": exchange_probe,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_detail": traffic_detail,
                      "kernel": PACK_KERNEL, "avg_ms": round(pack_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bpp * N},
         "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
-                           "note": "sum over ranks of the pack kernel rate (independent kernels, one per GPU)"},
+                           "note": "n_gpus x the slowest rank's pack kernel rate: a sum of independent per-GPU rates "
+                                   "(nothing shared is measured by it); `value` is the shared-file rate"},
         "snapshot_stall_ms": stall_ms,
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }
-    if world == 1 and not args.no_cpu_baseline and args.schema == "pvi":
-        out["cpu_baseline"] = cpu_baseline_reference(N, 64, args.dir) or cpu_baseline(N, 8, args.dir)
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if not args.no_cpu_baseline and args.schema == "pvi":
+        # the reference's CPU path on this host's cores: one MPI rank per GPU of the run (the other ranks of this
+        # run have left by now); a bounded sample (18 GB of file at most, 10-30 s)
+        out["cpu_baseline"] = (cpu_baseline_reference(N, max(4, 64 // world), args.dir, ranks=world)
+                               or cpu_baseline(N, 8, args.dir))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -210,7 +210,9 @@ extern "C"
        (all == false; copied) and all device chunks (packed into the staging arena at once,
        the kernel needs no offset).  ONE allgather at the next pgsd_end_frame (or pgsd_flush,
        pgsd_close, a read, a host chunk with all == true, a buffer-limit setter) carries every rank's
-       status word and the byte counts of all queued chunks; placement then replays the reference's
+       status word and the byte counts of all queued chunks (a fixed 512-byte message per rank whatever is
+       queued -- equal send counts, as ncclAllGather requires; only a frame of more than 62 queued chunks
+       takes further rounds); placement then replays the reference's
        decisions in call order, so the file is byte-identical to the unbatched one.  A frame of
        small chunks + device chunks + pgsd_end_frame costs ONE collective (one ncclAllGather on the
        RCCL back end, issued after the pack launch and overlapping it).  Consequences: the handle's
@@ -226,6 +228,15 @@ extern "C"
     /* Number of collectives (allgathers, barriers) this handle has issued on its communicator since it
        was opened: the evidence behind "one collective per frame" (bench.py, tests). */
     uint64_t pgsd_get_collective_count(struct pgsd_handle* handle);
+    /* What those allgathers cost the calling thread (wall clock around the communicator's allgather:
+       transport latency + the wait for the slowest rank): bench.py's `exchange_us`. */
+    struct pgsd_exchange_stats
+        {
+        uint64_t count;   /* allgathers since open / last reset */
+        double total_us;
+        double max_us;
+        };
+    int pgsd_get_exchange_stats(struct pgsd_handle* handle, struct pgsd_exchange_stats* out, int reset);
 
     /* reference pgsd.h:581-582.  The reference flushes first (collective).  Here the index is replicated:
        the call flushes (collectively) only while written chunks / names / index entries are still pending --

@@ -20,6 +20,7 @@
 #include "pgsd_internal.hpp"
 
 #include <cerrno>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
@@ -217,11 +218,22 @@ struct Impl
         }
 
     uint64_t n_collectives = 0; // allgathers / barriers this handle has issued (pgsd_get_collective_count)
+    // wall time of those allgathers as the calling thread sees it (pgsd_get_exchange_stats): transport
+    // latency plus the wait for the slowest rank to arrive
+    uint64_t exch_count = 0;
+    double exch_us_sum = 0, exch_us_max = 0;
 
     int gather(const void* send, void* recv, size_t bytes)
         {
         n_collectives++;
-        return comm.allgather(comm.ctx, send, recv, bytes);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = comm.allgather(comm.ctx, send, recv, bytes);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        exch_count++;
+        exch_us_sum += us;
+        if (us > exch_us_max)
+            exch_us_max = us;
+        return rc;
         }
 
     int allgather_u64(uint64_t v, std::vector<uint64_t>& out)
@@ -1064,28 +1076,63 @@ static int resolve_queue(Impl* s)
     {
     const size_t k = s->queue.size();
     const uint64_t FAILED = 1ull << 63;
-    std::vector<uint64_t> send(k + 2), recv;
+    // Every message of the exchange has the SAME length on every rank, whatever a rank has queued:
+    // ncclAllGather (like MPI_Allgather) is undefined for unequal send counts, so a rank that queued a
+    // different number of chunks -- a caller bug -- must be told apart by the CONTENT of a well-formed
+    // message, not by its size.  Round 0: [status, k, the first FRAME_SLOTS sizes, zero padded]; the usual
+    // frame (a handful of chunks) is done with it: ONE collective.  Only when all ranks agree on a k beyond
+    // FRAME_SLOTS do further rounds of FRAME_WORDS sizes each follow (their number follows from k alone).
+    enum
+        {
+        FRAME_WORDS = 64,
+        FRAME_SLOTS = FRAME_WORDS - 2
+        };
+    auto word_of = [&](size_t i) -> uint64_t
+    {
+        const Queued& q = s->queue[i];
+        return q.local_rc != PGSD_SUCCESS ? (FAILED | (uint64_t)(uint32_t)(-q.local_rc))
+                                          : q.N * q.M * sizeof_type(q.type);
+    };
+    std::vector<uint64_t> send(FRAME_WORDS, 0), recv;
     send[0] = (uint64_t)(uint32_t)s->sticky_rc | ((uint64_t)(uint32_t)s->sticky_errno << 32);
     send[1] = k;
-    for (size_t i = 0; i < k; i++)
-        {
-        const Queued& q = s->queue[i];
-        send[2 + i] = q.local_rc != PGSD_SUCCESS ? (FAILED | (uint64_t)(uint32_t)(-q.local_rc))
-                                                 : q.N * q.M * sizeof_type(q.type);
-        }
+    for (size_t i = 0; i < k && i < FRAME_SLOTS; i++)
+        send[2 + i] = word_of(i);
+    // sizes[r * k + i]: rank r's word for queued chunk i
+    std::vector<uint64_t> words((size_t)s->P * k, 0);
     int first_rc = PGSD_SUCCESS;
     if (s->P > 1)
         {
-        recv.assign((k + 2) * (size_t)s->P, 0);
-        bool comm_ok = s->gather(send.data(), recv.data(), send.size() * sizeof(uint64_t)) == 0;
+        recv.assign((size_t)FRAME_WORDS * (size_t)s->P, 0);
+        bool comm_ok = s->gather(send.data(), recv.data(), FRAME_WORDS * sizeof(uint64_t)) == 0;
         if (!comm_ok)
             set_last_error("communicator allgather failed");
         for (int r = 0; r < s->P && comm_ok; r++)
-            if (recv[(size_t)r * (k + 2) + 1] != k)
+            if (recv[(size_t)r * FRAME_WORDS + 1] != k)
                 {
                 set_last_error("the ranks queued different numbers of chunks for this frame");
                 comm_ok = false;
                 }
+        std::vector<uint64_t> status((size_t)s->P, 0);
+        for (int r = 0; r < s->P && comm_ok; r++)
+            {
+            status[(size_t)r] = recv[(size_t)r * FRAME_WORDS];
+            for (size_t i = 0; i < k && i < FRAME_SLOTS; i++)
+                words[(size_t)r * k + i] = recv[(size_t)r * FRAME_WORDS + 2 + i];
+            }
+        // frames of more than FRAME_SLOTS chunks: every rank knows by now that all ranks hold the same k
+        for (size_t base = FRAME_SLOTS; base < k && comm_ok; base += FRAME_WORDS)
+            {
+            std::fill(send.begin(), send.end(), 0);
+            for (size_t i = base; i < k && i < base + FRAME_WORDS; i++)
+                send[i - base] = word_of(i);
+            comm_ok = s->gather(send.data(), recv.data(), FRAME_WORDS * sizeof(uint64_t)) == 0;
+            if (!comm_ok)
+                set_last_error("communicator allgather failed");
+            for (int r = 0; r < s->P && comm_ok; r++)
+                for (size_t i = base; i < k && i < base + FRAME_WORDS; i++)
+                    words[(size_t)r * k + i] = recv[(size_t)r * FRAME_WORDS + (i - base)];
+            }
         if (!comm_ok)
             {
             // Nothing sane can be placed any more.  The queue is dropped (its borrowed row pointers die
@@ -1104,18 +1151,18 @@ static int resolve_queue(Impl* s)
         s->sticky_errno = 0;
         for (int r = 0; r < s->P; r++)
             {
-            const uint64_t* v = recv.data() + (size_t)r * (k + 2);
-            const int src = (int)(int32_t)(uint32_t)v[0];
+            const int src = (int)(int32_t)(uint32_t)status[(size_t)r];
             if (src != PGSD_SUCCESS && first_rc == PGSD_SUCCESS)
                 {
                 first_rc = src;
-                errno = (int)(uint32_t)(v[0] >> 32);
+                errno = (int)(uint32_t)(status[(size_t)r] >> 32);
                 }
             }
         }
     else
         {
-        recv = send;
+        for (size_t i = 0; i < k; i++)
+            words[i] = word_of(i);
         if (s->sticky_rc != PGSD_SUCCESS)
             {
             first_rc = s->sticky_rc;
@@ -1133,7 +1180,7 @@ static int resolve_queue(Impl* s)
         int bad = PGSD_SUCCESS;
         for (int r = 0; r < s->P; r++)
             {
-            const uint64_t e = recv[(size_t)r * (k + 2) + 2 + i];
+            const uint64_t e = words[(size_t)r * k + i];
             if (e & FAILED)
                 {
                 if (bad == PGSD_SUCCESS)
@@ -1756,6 +1803,27 @@ catch (...)
     {
         pgsd_amd::abi_guard();
         return 0;
+    }
+
+extern "C" int pgsd_get_exchange_stats(struct pgsd_handle* handle, struct pgsd_exchange_stats* out, int reset)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !out)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    out->count = s->exch_count;
+    out->total_us = s->exch_us_sum;
+    out->max_us = s->exch_us_max;
+    if (reset)
+        {
+        s->exch_count = 0;
+        s->exch_us_sum = s->exch_us_max = 0;
+        }
+    return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
     }
 
 extern "C" int pgsd_get_frame_exchange(struct pgsd_handle* handle)

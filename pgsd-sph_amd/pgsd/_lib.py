@@ -115,6 +115,10 @@ class DeviceStats(ctypes.Structure):
                 ("written_bytes", c_u64), ("d2h_ms", ctypes.c_double), ("write_ms", ctypes.c_double)]
 
 
+class ExchangeStats(ctypes.Structure):
+    _fields_ = [("count", c_u64), ("total_us", ctypes.c_double), ("max_us", ctypes.c_double)]
+
+
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_i32, c_vp, c_vp, c_vp, ctypes.c_size_t)
 BARRIER_FN = ctypes.CFUNCTYPE(c_i32, c_vp)
 DESTROY_FN = ctypes.CFUNCTYPE(None, c_vp)
@@ -183,6 +187,7 @@ _sig("pgsd_set_frame_exchange", c_i32, HP, c_i32)
 _sig("pgsd_get_frame_exchange", c_i32, HP)
 _sig("pgsd_frame_exchange", c_i32, HP)
 _sig("pgsd_get_collective_count", c_u64, HP)
+_sig("pgsd_get_exchange_stats", c_i32, HP, ctypes.POINTER(ExchangeStats), c_i32)
 _sig("pgsd_unpack_fields", c_i32, c_u32, ctypes.POINTER(UnpackJob), c_u64, c_vp)
 _sig("pgsd_read_chunk_device", c_i32, HP, ctypes.POINTER(IndexEntry), c_u64, c_u64, ctypes.POINTER(FieldDst))
 _sig("pgsd_device_wait_read", c_i32, HP)

@@ -367,6 +367,14 @@ class PGSDFile(object):
         self._check_open()
         return int(lib.pgsd_get_collective_count(self._h()))
 
+    def exchange_stats(self, reset=False):
+        """dict ``count``, ``total_us``, ``max_us``: the allgathers this handle issued and their wall time on this
+        rank (transport latency + the wait for the slowest rank)."""
+        self._check_open()
+        st = _lib.ExchangeStats()
+        _raise_on_error(lib.pgsd_get_exchange_stats(self._h(), ctypes.byref(st), 1 if reset else 0), self.__name)
+        return {"count": int(st.count), "total_us": float(st.total_us), "max_us": float(st.max_us)}
+
     # ------------------------------------------------------------------ writing
     def write_chunk(self, name, data, offset=None, rank=0, write_all=True):
         """Write a data chunk to the current frame (fl.pyx:526-654).

@@ -13,6 +13,9 @@ from pgsd import _lib
 import pgsd.fl as fl
 
 
+FRAME_MESSAGE = 512     # bytes per rank of a frame exchange (64 words: status, count, 62 sizes), pgsd_file.cpp
+
+
 class MirrorComm:
     """rank 0 of 2; the peer mirrors rank 0's contribution"""
 
@@ -84,13 +87,68 @@ def test_batched_frames_of_small_chunks_exchange_once_and_match_the_unbatched_fi
             f.end_frame()
         if batched:
             assert len(mirror.calls) - n0 == 5          # one exchange per frame (3 sizes + status + count)
-            assert mirror.calls[-1] == 8 * (2 + 3)
+            assert mirror.calls[-1] == FRAME_MESSAGE    # ... of the fixed length, whatever is queued
         else:
             assert len(mirror.calls) - n0 == 15         # one per chunk; small chunks alone never flush
         f.close()
         paths.append(p)
     with open(paths[0], "rb") as a, open(paths[1], "rb") as b:
         assert a.read() == b.read()
+
+
+def test_frame_exchange_messages_have_one_length_whatever_is_queued(mirror, tmp_path):
+    """ncclAllGather (and MPI_Allgather) need equal send counts on all ranks: the frame exchange never sends a
+    message whose length depends on what THIS rank queued.  0, 1, 5, 62 chunks: one
+    512-byte message; 63, 130 chunks: further rounds of the same length; file == the unbatched one."""
+    for n_chunks in (1, 5, 62, 63, 130):
+        paths = []
+        for batched in (False, True):
+            p = str(tmp_path / ("m%d_%d.gsd" % (n_chunks, batched)))
+            f = fl.open(p, "w", application="app", schema="hoomd", schema_version=[1, 4])
+            f.frame_exchange = batched
+            n0 = len(mirror.calls)
+            for fr in range(2):
+                for c in range(n_chunks):
+                    f.write_chunk("log/q%03d" % c, np.arange(c % 7 + 1, dtype=np.float32) + fr, write_all=False)
+                f.end_frame()
+            if batched:
+                rounds = 1 if n_chunks <= 62 else 1 + -(-(n_chunks - 62) // 64)
+                assert mirror.calls[n0:] == [FRAME_MESSAGE] * (2 * rounds), (n_chunks, mirror.calls[n0:])
+            f.close()
+            paths.append(p)
+        with open(paths[0], "rb") as a, open(paths[1], "rb") as b:
+            assert a.read() == b.read(), n_chunks
+
+
+def test_ranks_that_queued_different_numbers_of_chunks_are_told_apart_by_content(tmp_path):
+    """A peer that queued one chunk fewer still sends a well-formed message of the common length; the count
+    word gives it away and the call fails with PGSD_ERROR_COMM instead of an allgather of unequal sizes."""
+    lengths = []
+
+    def allgather(ctx, send, recv, nbytes):
+        lengths.append(nbytes)
+        ctypes.memmove(recv, send, nbytes)
+        ctypes.memmove(recv + nbytes, send, nbytes)
+        if nbytes == FRAME_MESSAGE:
+            words = (ctypes.c_uint64 * 64).from_address(recv + nbytes)
+            words[1] -= 1                      # the peer's count
+        return 0
+
+    ag = _lib.ALLGATHER_FN(allgather)
+    comm = _lib.Comm()
+    comm.ctx, comm.rank, comm.size, comm.allgather = None, 0, 2, ag
+    assert _lib.lib.pgsd_comm_set_default(ctypes.byref(comm)) == 0
+    try:
+        f = fl.open(str(tmp_path / "k.gsd"), "w", application="app", schema="hoomd", schema_version=[1, 4])
+        f.frame_exchange = True
+        small_frame(f, 0)
+        with pytest.raises(RuntimeError, match="different numbers of chunks"):
+            f.end_frame()
+        assert lengths[-1] == FRAME_MESSAGE
+        stats = f.exchange_stats()
+        assert stats["count"] == f.collective_count and stats["max_us"] >= 0 and stats["total_us"] >= stats["max_us"]
+    finally:
+        _lib.lib.pgsd_comm_finalize()
 
 
 def test_auto_partition_equals_the_callers_allgather(mirror, tmp_path):
@@ -151,7 +209,7 @@ def test_one_collective_per_device_frame(empty_peer, tmp_gsd):
         f.write_chunks(fields, offset="auto")
         f.end_frame()
         assert len(mirror.calls) - n0 == 1
-        assert mirror.calls[-1] == 8 * (2 + 4)          # status, count, four chunk sizes
+        assert mirror.calls[-1] == FRAME_MESSAGE        # status, count, four chunk sizes, padding
     f.close()
     g = fl.open(tmp_gsd, "r")
     got = g.read_chunk(2, "particles/position")

@@ -53,3 +53,39 @@ def test_bench_measures_its_hbm_traffic_with_the_pmc_counters():
     assert abs(det["write_bytes"] - 28 * n) < 0.02 * 28 * n          # the three chunks
     assert abs(det["read_bytes"] - 32 * n) < 0.05 * 32 * n           # two float4 arrays
     assert r["traffic"] == det["read_bytes"] + det["write_bytes"]
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself.  The box has one GPU: without the
+    rehearsal flag that is refused (one rank per GPU is the contract), with it both ranks share cuda:0 over a gloo
+    group and the line says n_gpus 2, one collective per frame, and what that collective cost."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+            "--particles", "200000", "--traffic", "off"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode != 0 and p.stdout.strip() == ""
+        assert "this node shows 1 GPU" in p.stderr and "--rehearse-shared-gpu" in p.stderr
+    p = subprocess.run(base + ["--rehearse-shared-gpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collectives_per_frame"] == 1.0 and d["comm_backend"] == "torch-gloo"
+    x = d["exchange_us"]
+    assert x["per_rank_count"] == 3 and 0 < x["mean_fastest_rank"] <= x["mean"] <= x["max"] and x["bytes_per_rank"] == 512
+    c = d["cpu_baseline"]
+    assert c["nproc"] >= 1 and c["value"] > 0
+    if c["kind"] == "reference":                    # P host ranks for P GPUs (SURVEY 8(d)); the port is one thread
+        assert c["ranks"] == 2 and c["cores"] == 2 and c["more_cores"]["ranks"] >= 2
+    assert d["config"]["parallelism"] == "particle-partition x2"
+
+
+def test_single_rank_line_carries_the_exchange_probe():
+    d = run_bench("--traffic", "off", "--no-cpu-baseline")
+    assert d["exchange_us"] is None                 # one rank: no exchange
+    pr = d["exchange_probe"]
+    if pr is None:
+        pytest.skip("no RCCL on this box")
+    assert pr["bytes"] == 512 and 0 < pr["min_us"] <= pr["median_us"] <= pr["p99_us"]
