@@ -235,6 +235,7 @@ extern "C"
         uint64_t count;   /* allgathers since open / last reset */
         double total_us;
         double max_us;
+        double min_us;    /* the quickest one: a rank that arrived last waits for nobody */
         };
     int pgsd_get_exchange_stats(struct pgsd_handle* handle, struct pgsd_exchange_stats* out, int reset);
 

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <string>
@@ -77,6 +78,64 @@ int abi_guard() noexcept
     return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
     }
 
+// ---------------------------------------------------------------- phase timeline (roctx)
+namespace
+    {
+struct Roctx
+    {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    Roctx()
+        {
+        const char* e = getenv("PGSD_TRACE");
+        if (!e || !*e || atoi(e) == 0)
+            return;
+        void* lib = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                              "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"})
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+                break;
+        if (!lib)
+            return;
+        push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        on = push && pop;
+        }
+    };
+
+const Roctx& roctx()
+    {
+    static const Roctx r;
+    return r;
+    }
+    } // namespace
+
+bool trace_on()
+    {
+    return roctx().on;
+    }
+
+void trace_push(const char* name)
+    {
+    (void)roctx().push(name);
+    }
+
+void trace_pop()
+    {
+    (void)roctx().pop();
+    }
+
+TraceRange::TraceRange(const char* fmt, unsigned long long a, unsigned long long b) : on(trace_on())
+    {
+    if (on)
+        {
+        char buf[160];
+        snprintf(buf, sizeof(buf), fmt, a, b);
+        trace_push(buf);
+        }
+    }
+
 // ---------------------------------------------------------------- self
 static int self_allgather(void*, const void* send, void* recv, size_t bytes)
     {
@@ -97,8 +156,13 @@ static pgsd_comm make_self()
 
 static std::shared_ptr<CommBox>& comm_slot()
     {
-    static std::shared_ptr<CommBox> box = std::make_shared<CommBox>(make_self());
-    return box;
+    // Leaked on purpose: a process that exits without pgsd_comm_finalize must not run a communicator's
+    // destroy hook from static destruction -- librccl (dlopen'ed later than this library) has torn itself
+    // down by then, ncclCommDestroy is not safe when ranks exit at different times, and the shm back end's
+    // destroy hook is a barrier.  Teardown happens in pgsd_comm_finalize / pgsd_comm_init_* or when the last
+    // handle that outlived its communicator is closed; at exit the OS takes the rest.
+    static std::shared_ptr<CommBox>* box = new std::shared_ptr<CommBox>(std::make_shared<CommBox>(make_self()));
+    return *box;
     }
 
 std::shared_ptr<CommBox> default_comm_box()

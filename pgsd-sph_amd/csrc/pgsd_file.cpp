@@ -221,7 +221,7 @@ struct Impl
     // wall time of those allgathers as the calling thread sees it (pgsd_get_exchange_stats): transport
     // latency plus the wait for the slowest rank to arrive
     uint64_t exch_count = 0;
-    double exch_us_sum = 0, exch_us_max = 0;
+    double exch_us_sum = 0, exch_us_max = 0, exch_us_min = 0;
 
     int gather(const void* send, void* recv, size_t bytes)
         {
@@ -233,6 +233,8 @@ struct Impl
         exch_us_sum += us;
         if (us > exch_us_max)
             exch_us_max = us;
+        if (exch_count == 1 || us < exch_us_min)
+            exch_us_min = us;
         return rc;
         }
 
@@ -669,7 +671,10 @@ static int do_flush(Impl* s, bool async = false, bool sync_point = true)
     int sticky_errno = 0;
     // device chunks of this rank must be in the file before the frame is sealed
     if (s->dev && async)
+        {
         s->inflight = true;
+        device_pipeline_kick(s->dev);
+        }
     else if (s->dev)
         {
         s->inflight = false;
@@ -803,6 +808,7 @@ static int do_end_frame(Impl* s, bool async = false)
     // pgsd.c:1916-1953
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
+    TraceRange tr("pgsd:end_frame frame=%llu", s->cur_frame);
     // queued chunks belong to the frame that is being sealed: place them before the counter moves
     const int qrc = s->queue.empty() ? PGSD_SUCCESS : resolve_queue(s);
     s->cur_frame++;
@@ -1055,6 +1061,7 @@ static int deliver_chunk(Impl* s, Queued& q, const Placement& pl, bool skip)
     if (!pl.write)
         return PGSD_SUCCESS;
     // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
+    TraceRange tr("pgsd:pwrite_host file_off=%llu bytes=%llu", (unsigned long long)pl.file_offset, pl.size);
     int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
     if (e != 0)
         {
@@ -1104,6 +1111,7 @@ static int resolve_queue(Impl* s)
     if (s->P > 1)
         {
         recv.assign((size_t)FRAME_WORDS * (size_t)s->P, 0);
+        TraceRange tr("pgsd:frame_exchange chunks=%llu ranks=%llu", k, (unsigned long long)s->P);
         bool comm_ok = s->gather(send.data(), recv.data(), FRAME_WORDS * sizeof(uint64_t)) == 0;
         if (!comm_ok)
             set_last_error("communicator allgather failed");
@@ -1814,10 +1822,11 @@ extern "C" int pgsd_get_exchange_stats(struct pgsd_handle* handle, struct pgsd_e
     out->count = s->exch_count;
     out->total_us = s->exch_us_sum;
     out->max_us = s->exch_us_max;
+    out->min_us = s->exch_us_min;
     if (reset)
         {
         s->exch_count = 0;
-        s->exch_us_sum = s->exch_us_max = 0;
+        s->exch_us_sum = s->exch_us_max = s->exch_us_min = 0;
         }
     return PGSD_SUCCESS;
     }

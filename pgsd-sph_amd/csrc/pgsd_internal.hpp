@@ -36,6 +36,33 @@ struct CommBox
     };
 std::shared_ptr<CommBox> default_comm_box();
 
+// ---- phase timeline: roctx ranges around the phases of a frame (pack launch, frame exchange, each
+// device->host piece, each pwrite, drain), the counterpart of the reference's PGSD_ACTIVATE_LOGGER
+// output (pgsd.c:27, 1034, 1156, 2231).  Off unless PGSD_TRACE is set to a non-zero value; then
+// librocprofiler-sdk-roctx is dlopen'ed (no link-time dependency) and `rocprofv3 --marker-trace` shows
+// the ranges next to the kernels and copies they bracket.
+bool trace_on();
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange
+    {
+    bool on;
+    explicit TraceRange(const char* name) : on(trace_on())
+        {
+        if (on)
+            trace_push(name);
+        }
+    // name with one number (piece offset, byte count ...): formatted only when tracing
+    TraceRange(const char* fmt, unsigned long long a, unsigned long long b = 0);
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    ~TraceRange()
+        {
+        if (on)
+            trace_pop();
+        }
+    };
+
 inline int comm_barrier(const pgsd_comm& c)
     {
     if (c.size == 1)
@@ -82,6 +109,8 @@ int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, ui
 int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, int* ticket, std::string* err);
 int device_pipeline_commit(DevicePipeline*, int ticket, size_t index, long long file_offset, void* host_dst,
                            std::string* err);
+// asynchronous seal: chunks of the direct (small-frame) path are handed to the writer thread now
+void device_pipeline_kick(DevicePipeline*);
 int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
 void device_pipeline_set_source_stream(DevicePipeline*, void* stream);
 // read side: rows at `file_offset` -> staging -> unpack into job.dst (job.src is filled in)

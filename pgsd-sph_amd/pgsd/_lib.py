@@ -116,7 +116,8 @@ class DeviceStats(ctypes.Structure):
 
 
 class ExchangeStats(ctypes.Structure):
-    _fields_ = [("count", c_u64), ("total_us", ctypes.c_double), ("max_us", ctypes.c_double)]
+    _fields_ = [("count", c_u64), ("total_us", ctypes.c_double), ("max_us", ctypes.c_double),
+                ("min_us", ctypes.c_double)]
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_i32, c_vp, c_vp, c_vp, ctypes.c_size_t)

@@ -368,12 +368,13 @@ class PGSDFile(object):
         return int(lib.pgsd_get_collective_count(self._h()))
 
     def exchange_stats(self, reset=False):
-        """dict ``count``, ``total_us``, ``max_us``: the allgathers this handle issued and their wall time on this
+        """dict ``count``, ``total_us``, ``max_us``, ``min_us``: the allgathers this handle issued and their wall time on this
         rank (transport latency + the wait for the slowest rank)."""
         self._check_open()
         st = _lib.ExchangeStats()
         _raise_on_error(lib.pgsd_get_exchange_stats(self._h(), ctypes.byref(st), 1 if reset else 0), self.__name)
-        return {"count": int(st.count), "total_us": float(st.total_us), "max_us": float(st.max_us)}
+        return {"count": int(st.count), "total_us": float(st.total_us), "max_us": float(st.max_us),
+                "min_us": float(st.min_us)}
 
     # ------------------------------------------------------------------ writing
     def write_chunk(self, name, data, offset=None, rank=0, write_all=True):

@@ -74,7 +74,8 @@ def test_gpus_flag_launches_that_many_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collectives_per_frame"] == 1.0 and d["comm_backend"] == "torch-gloo"
     x = d["exchange_us"]
-    assert x["per_rank_count"] == 3 and 0 < x["mean_fastest_rank"] <= x["mean"] <= x["max"] and x["bytes_per_rank"] == 512
+    assert x["per_rank_count"] == 3 and 0 < x["min"] <= x["mean_fastest_rank"] <= x["mean"] <= x["max"]
+    assert x["bytes_per_rank"] == 512
     c = d["cpu_baseline"]
     assert c["nproc"] >= 1 and c["value"] > 0
     if c["kind"] == "reference":                    # P host ranks for P GPUs; the port is one thread
