@@ -316,6 +316,30 @@ extern "C"
     int pgsd_comm_allgather(const void* send, void* recv, size_t bytes);
     int pgsd_comm_barrier(void);
 
+    /* Communicators that are NOT the process default: several ranks in ONE process (one thread per GPU, each
+       with a handle of its own), or independent groups of ranks side by side.  pgsd_comm_create_* fill in
+       `out` without installing anything; pgsd_create_and_open_on / pgsd_open_on open a file on such a
+       communicator (the struct is copied; the caller keeps the communicator alive until every handle opened
+       on it is closed, then lets it go with pgsd_comm_release).  Everything else is as with the default
+       communicator: the pgsd_* calls on the handle are collective over ITS communicator. */
+    int pgsd_comm_create_shm(const char* name, int rank, int size, struct pgsd_comm* out);
+    int pgsd_comm_create_rccl(const void* unique_id_128, int rank, int size, int device, struct pgsd_comm* out);
+    void pgsd_comm_release(struct pgsd_comm* comm);
+    int pgsd_create_and_open_on(const struct pgsd_comm* comm,
+                                struct pgsd_handle* handle,
+                                const char* fname,
+                                const char* application,
+                                const char* schema,
+                                uint32_t schema_version,
+                                enum pgsd_open_flag flags,
+                                int exclusive_create);
+    int pgsd_open_on(const struct pgsd_comm* comm, struct pgsd_handle* handle, const char* fname,
+                     enum pgsd_open_flag flags);
+    /* An allgather over the communicator `handle` was opened on (counted among its collectives): what a
+       caller-side exchange that belongs to the file -- pgsd.hoomd's row counts and write/skip votes -- uses
+       instead of the process default. */
+    int pgsd_handle_allgather(struct pgsd_handle* handle, const void* send, void* recv, size_t bytes);
+
     /* The per-frame exchange of the reference's callers (benchmark-write.cc:39-45,
        fl.pyx:596-598): allgather every rank's local row count; returns the exclusive
        prefix (this rank's first row) and the total.  counts may be NULL. */

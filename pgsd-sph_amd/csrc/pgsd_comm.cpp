@@ -365,7 +365,7 @@ enum
     SHM_RETRY = 1
     };
 
-static int shm_attach(const char* name, int rank, int size, int attempt)
+static int shm_attach(const char* name, int rank, int size, int attempt, pgsd_comm* out)
     {
     std::string nm = name[0] == '/' ? name : std::string("/") + name;
     size_t bytes = sizeof(ShmSegment) + (size_t)size * SHM_SLOT_BYTES;
@@ -490,7 +490,31 @@ static int shm_attach(const char* name, int rank, int size, int attempt)
     pc.allgather = shm_allgather;
     pc.barrier = shm_barrier;
     pc.destroy = shm_destroy;
+    if (out)
+        {
+        *out = pc;
+        return PGSD_SUCCESS;
+        }
     return comm_install(pc);
+    }
+
+static int shm_open_comm(const char* name, int rank, int size, pgsd_comm* out)
+    {
+    if (!name || size < 1 || rank < 0 || rank >= size)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (size > SHM_MAX_RANKS)
+        {
+        set_last_error("the shm communicator takes at most 1024 ranks");
+        return PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    for (int attempt = 0;; attempt++)
+        {
+        int rc = shm_attach(name, rank, size, attempt, out);
+        if (rc != SHM_RETRY)
+            return rc;
+        struct timespec nap = {0, 10000000};
+        nanosleep(&nap, NULL);
+        }
     }
 
 extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
@@ -500,23 +524,42 @@ extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (size == 1)
         return pgsd_comm_init_self();
-    if (size > SHM_MAX_RANKS)
-        {
-        set_last_error("the shm communicator takes at most 1024 ranks");
-        return PGSD_ERROR_INVALID_ARGUMENT;
-        }
-    for (int attempt = 0;; attempt++)
-        {
-        int rc = shm_attach(name, rank, size, attempt);
-        if (rc != SHM_RETRY)
-            return rc;
-        struct timespec nap = {0, 10000000};
-        nanosleep(&nap, NULL);
-        }
+    return shm_open_comm(name, rank, size, nullptr);
     }
 catch (...)
     {
         return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_comm_create_shm(const char* name, int rank, int size, struct pgsd_comm* out)
+    try
+    {
+    if (!out)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (size == 1 && name && rank == 0)
+        {
+        *out = make_self();
+        return PGSD_SUCCESS;
+        }
+    return shm_open_comm(name, rank, size, out);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" void pgsd_comm_release(struct pgsd_comm* comm)
+    try
+    {
+    if (!comm)
+        return;
+    if (comm->destroy)
+        comm->destroy(comm->ctx);
+    memset(comm, 0, sizeof(*comm));
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
     }
 
 extern "C" int pgsd_comm_init_from_env(void)

@@ -188,8 +188,33 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
+static int rccl_open_comm(const void* unique_id_128, int rank, int size, int device, pgsd_comm* out);
+
 extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device)
     try
+    {
+    pgsd_comm pc;
+    int rc = rccl_open_comm(unique_id_128, rank, size, device, &pc);
+    return rc == PGSD_SUCCESS ? pgsd_comm_set_default(&pc) : rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_comm_create_rccl(const void* unique_id_128, int rank, int size, int device, struct pgsd_comm* out)
+    try
+    {
+    if (!out)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    return rccl_open_comm(unique_id_128, rank, size, device, out);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+static int rccl_open_comm(const void* unique_id_128, int rank, int size, int device, pgsd_comm* out)
     {
     if (!unique_id_128 || size < 1 || rank < 0 || rank >= size)
         return PGSD_ERROR_INVALID_ARGUMENT;
@@ -229,9 +254,6 @@ extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size
     pc.allgather = rccl_allgather;
     pc.barrier = nullptr; // 1-byte allgather
     pc.destroy = rccl_destroy;
-    return pgsd_comm_set_default(&pc);
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
+    *out = pc;
+    return PGSD_SUCCESS;
     }

@@ -182,6 +182,38 @@ struct ReadEngine
         }
     };
 
+// What a pipeline needs from the HIP runtime is expensive to make and to give back: two streams (ms each),
+// pinned slabs (2-3 ms per 16 MiB hipHostMalloc, more to free), the pinned arena of the direct path, an HBM
+// arena, events.  A trajectory writer that opens one file per snapshot (or a benchmark that re-creates its
+// file) paid 20-30 ms per open/close for them.  A closed pipeline of the default geometry therefore parks its
+// resources here, at most two sets per process, and the next pipeline on the same device adopts them.
+// Never freed at exit: no HIP calls from static destruction.
+struct ParkedResources
+    {
+    int device = -1;
+    uint64_t slab_bytes = 0;
+    hipStream_t pack_stream = nullptr, copy_stream = nullptr;
+    std::vector<std::pair<char*, hipEvent_t>> slabs; // pinned slab + its copy event
+    char* dhost = nullptr;
+    char* ddev = nullptr;
+    size_t dcap = 0;
+    char* arena = nullptr;
+    size_t arena_cap = 0;
+    std::vector<hipEvent_t> ev_plain, ev_timing;
+    };
+
+static std::mutex& parked_mutex()
+    {
+    static std::mutex* m = new std::mutex;
+    return *m;
+    }
+
+static std::vector<ParkedResources>& parked()
+    {
+    static std::vector<ParkedResources>* v = new std::vector<ParkedResources>;
+    return *v;
+    }
+
 class DevicePipeline
     {
     public:
@@ -210,8 +242,35 @@ class DevicePipeline
         m_direct_max = (size_t)2048 << 10;
         if (const char* v = getenv("PGSD_DIRECT_MAX_KIB"))
             m_direct_max = (size_t)(atoll(v) > 0 ? atoll(v) : 0) << 10;
-        HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
+        ParkedResources adopted;
+        bool have_parked = false;
+            {
+            std::lock_guard<std::mutex> g(parked_mutex());
+            auto& v = parked();
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i].device == m_cfg.device && v[i].slab_bytes == m_cfg.slab_bytes)
+                    {
+                    adopted = std::move(v[i]);
+                    v.erase(v.begin() + (long)i);
+                    have_parked = true;
+                    break;
+                    }
+            }
+        if (have_parked)
+            {
+            m_pack_stream = adopted.pack_stream;
+            m_copy_stream = adopted.copy_stream;
+            m_dhost = adopted.dhost, m_ddev = adopted.ddev, m_dcap = adopted.dcap;
+            if (adopted.arena)
+                m_arenas.push_back({adopted.arena, adopted.arena_cap, 0});
+            m_pool_plain = std::move(adopted.ev_plain);
+            m_pool_timing = std::move(adopted.ev_timing);
+            }
+        else
+            {
+            HIP_TRY(hipStreamCreateWithFlags(&m_pack_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&m_copy_stream, hipStreamNonBlocking));
+            }
         // The pinned slabs, the thread that copies them into the page cache and the pages it
         // allocates there all belong on the NUMA node the GPU hangs off (two-socket hosts: the
         // other node costs ~10 % of the write rate, profiles/r01_numa.log).
@@ -219,32 +278,68 @@ class DevicePipeline
         m_numa = hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), m_cfg.device) == hipSuccess
                  && numa_cpus_of_pci_device(bdf, &m_numa_cpus);
         m_slabs.resize(m_cfg.n_slabs);
-        hipError_t alloc_err = hipSuccess;
-        std::thread allocator(
-            [&]
+        // parked slabs first (already pinned on this device's NUMA node); what the ring cannot take is freed
+        for (auto& ps : adopted.slabs)
             {
-                // first touch decides the node: allocate from a thread that runs there
-                if (m_numa)
-                    (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
-                (void)hipSetDevice(m_cfg.device);
-                // two slabs now; the dispatcher (pinned to the same node) adds the rest of the ring
-                // when a frame actually needs them, so a small file never pins 256 MiB
-                for (uint32_t i = 0; i < m_cfg.n_slabs && i < 2; i++)
-                    {
-                    hipError_t e = alloc_slab(m_slabs[i]);
-                    if (e != hipSuccess && alloc_err == hipSuccess)
-                        alloc_err = e;
-                    }
-            });
-        allocator.join();
-        HIP_TRY(alloc_err);
-        m_slabs_ready = std::min<uint32_t>(m_cfg.n_slabs, 2);
+            if (m_slabs_ready < m_cfg.n_slabs)
+                {
+                m_slabs[m_slabs_ready].host = ps.first;
+                m_slabs[m_slabs_ready].copied = ps.second;
+                m_slabs_ready++;
+                }
+            else
+                {
+                (void)hipEventDestroy(ps.second);
+                (void)hipHostFree(ps.first);
+                }
+            }
+        if (m_slabs_ready < std::min<uint32_t>(m_cfg.n_slabs, 2))
+            {
+            hipError_t alloc_err = hipSuccess;
+            std::thread allocator(
+                [&]
+                {
+                    // first touch decides the node: allocate from a thread that runs there
+                    if (m_numa)
+                        (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &m_numa_cpus);
+                    (void)hipSetDevice(m_cfg.device);
+                    // two slabs now; the dispatcher (pinned to the same node) adds the rest of the ring
+                    // when a frame actually needs them, so a small file never pins 256 MiB
+                    while (m_slabs_ready < m_cfg.n_slabs && m_slabs_ready < 2)
+                        {
+                        hipError_t e = alloc_slab(m_slabs[m_slabs_ready]);
+                        if (e != hipSuccess)
+                            {
+                            alloc_err = e;
+                            break;
+                            }
+                        m_slabs_ready++;
+                        }
+                });
+            allocator.join();
+            HIP_TRY(alloc_err);
+            }
         for (uint32_t i = 0; i < m_slabs_ready; i++)
             m_free_slabs.push_back(i);
-        m_pool = writer_pool_create(m_cfg.n_writers, m_numa ? &m_numa_cpus : nullptr);
+        // EXPERIMENT (PGSD_WARMERS=n): a slab the SDMA engine has just filled is cold for the CPU -- every line
+        // comes from DRAM while the writer's pwrite copies it into the page cache (6-7 GB/s), whereas the same
+        // pwrite from cache-warm memory runs at 12-15 GB/s (the host path on an L3-resident array).  n warmer
+        // threads on cores that share the writer's L3 read each landed piece once before it is handed on.
+        unsigned warmers = 0;
+        if (const char* v = getenv("PGSD_WARMERS"))
+            warmers = (unsigned)(atoi(v) > 0 ? atoi(v) : 0);
+        const cpu_set_t* pin = m_numa ? &m_numa_cpus : nullptr;
+        if (warmers)
+            {
+            m_l3 = l3_cpus(pin, &m_l3_cpus);
+            if (m_l3)
+                pin = &m_l3_cpus;
+            m_warm_pool = writer_pool_create(warmers, pin);
+            }
+        m_pool = writer_pool_create(m_cfg.n_writers, pin);
         m_dispatcher = std::thread([this] { dispatch_loop(); });
-        if (m_numa)
-            (void)pthread_setaffinity_np(m_dispatcher.native_handle(), sizeof(cpu_set_t), &m_numa_cpus);
+        if (pin)
+            (void)pthread_setaffinity_np(m_dispatcher.native_handle(), sizeof(cpu_set_t), pin);
         m_ok = true;
         return PGSD_SUCCESS;
         }
@@ -270,10 +365,14 @@ class DevicePipeline
                 }
             ReadEngine::release(m_reader);
             }
+        if (m_warm_pool)
+            writer_pool_destroy(m_warm_pool); // joins the warmers (they feed the writers)
         if (m_pool)
             writer_pool_destroy(m_pool); // joins the writers
         (void)hipSetDevice(m_cfg.device);
         release_events();
+        if (park())
+            return;
         for (hipEvent_t e : m_pool_plain)
             (void)hipEventDestroy(e);
         for (hipEvent_t e : m_pool_timing)
@@ -293,6 +392,58 @@ class DevicePipeline
             (void)hipStreamDestroy(m_pack_stream);
         if (m_copy_stream)
             (void)hipStreamDestroy(m_copy_stream);
+        }
+
+    // Hand streams, pinned memory, one HBM arena and the idle events to the next pipeline on this device
+    // (see ParkedResources).  Only a healthy pipeline of the default slab size, only while fewer than two sets
+    // are parked, and only what a default pipeline would hold: at most four slabs, one arena of the default size.
+    bool park()
+        {
+        const uint64_t default_slab = (uint64_t)16 << 20;
+        if (!m_ok || !m_error.empty() || m_cfg.slab_bytes != default_slab || !m_pack_stream || !m_copy_stream)
+            return false;
+        if (getenv("PGSD_NO_PARKING"))
+            return false;
+        if (hipStreamSynchronize(m_pack_stream) != hipSuccess || hipStreamSynchronize(m_copy_stream) != hipSuccess)
+            {
+            (void)hipGetLastError();
+            return false;
+            }
+        ParkedResources r;
+        r.device = m_cfg.device;
+        r.slab_bytes = m_cfg.slab_bytes;
+            {
+            std::lock_guard<std::mutex> g(parked_mutex());
+            if (parked().size() >= 2)
+                return false;
+            }
+        r.pack_stream = m_pack_stream;
+        r.copy_stream = m_copy_stream;
+        for (auto& sl : m_slabs)
+            {
+            if (!sl.host)
+                continue;
+            if (r.slabs.size() < 4)
+                r.slabs.push_back({sl.host, sl.copied});
+            else
+                {
+                (void)hipEventDestroy(sl.copied);
+                (void)hipHostFree(sl.host);
+                }
+            }
+        r.dhost = m_dhost, r.ddev = m_ddev, r.dcap = m_dcap;
+        for (auto& a : m_arenas)
+            {
+            if (!r.arena && a.cap == ((size_t)256 << 20))
+                r.arena = a.base, r.arena_cap = a.cap;
+            else
+                (void)hipFree(a.base);
+            }
+        r.ev_plain = std::move(m_pool_plain);
+        r.ev_timing = std::move(m_pool_timing);
+        std::lock_guard<std::mutex> g(parked_mutex());
+        parked().push_back(std::move(r));
+        return true;
         }
 
     // Pack now, place later.  stage() packs the chunks into the staging arena with one fused launch and
@@ -1003,7 +1154,10 @@ class DevicePipeline
                     continue;
                     }
                 long long foff = job.file_offset + (long long)off;
-                writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
+                if (m_warm_pool)
+                    writer_pool_submit(m_warm_pool, [this, si, n, foff] { warm_piece(si, n, foff); });
+                else
+                    writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
                 }
             if (c0 && c1)
                 {
@@ -1146,6 +1300,29 @@ class DevicePipeline
         read_done();
         }
 
+    // warmer thread: wait for the piece to land, read every cache line of it once (into the L3 this thread
+    // shares with the writer), hand it to the writer
+    void warm_piece(int si, size_t n, long long foff)
+        {
+        (void)hipSetDevice(m_cfg.device);
+        Slab& s = m_slabs[(size_t)si];
+        if (hipEventSynchronize(s.copied) == hipSuccess)
+            {
+            TraceRange tr("pgsd:warm file_off=%llu bytes=%llu", (unsigned long long)foff, n);
+            const volatile uint64_t* p = (const volatile uint64_t*)s.host;
+            uint64_t acc = 0;
+            const size_t words = n / 8;
+            // four independent streams a page apart keep more misses in flight than one sequential walk
+            const size_t q = (words / 4) & ~(size_t)7;
+            for (size_t i = 0; i < q; i += 8)
+                acc += p[i] + p[q + i] + p[2 * q + i] + p[3 * q + i];
+            for (size_t i = 4 * q; i < words; i += 8)
+                acc += p[i];
+            m_warm_sink += acc;
+            }
+        writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
+        }
+
     void write_piece(int si, size_t n, long long foff)
         {
         (void)hipSetDevice(m_cfg.device);
@@ -1214,6 +1391,10 @@ class DevicePipeline
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
     hipEvent_t m_direct_packed = nullptr;  // pack event of the newest of them
     WriterPool* m_pool = nullptr;
+    WriterPool* m_warm_pool = nullptr; // PGSD_WARMERS experiment
+    bool m_l3 = false;
+    cpu_set_t m_l3_cpus;
+    volatile uint64_t m_warm_sink = 0;
     ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device
     std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
     size_t m_reads_outstanding = 0;

@@ -471,10 +471,18 @@ static void destroy_impl(Impl* s)
     delete s;
     }
 
-static Impl* new_impl()
+static Impl* new_impl(const pgsd_comm* on = nullptr)
     {
     Impl* s = new Impl;
-    s->comm_box = default_comm_box();
+    if (on)
+        {
+        // a communicator of the caller's (pgsd_create_and_open_on): copied, never destroyed by the handle
+        pgsd_comm c = *on;
+        c.destroy = nullptr;
+        s->comm_box = std::make_shared<CommBox>(c);
+        }
+    else
+        s->comm_box = default_comm_box();
     s->comm = s->comm_box->c;
     s->rank = s->comm.rank;
     s->P = s->comm.size;
@@ -1256,10 +1264,80 @@ catch (...)
         return 0;
     }
 
+static bool comm_usable(const pgsd_comm* c)
+    {
+    return c && c->allgather && c->size >= 1 && c->rank >= 0 && c->rank < c->size;
+    }
+
+static int create_and_open(const pgsd_comm* on, struct pgsd_handle* handle, const char* fname, const char* application,
+                           const char* schema, uint32_t schema_version, enum pgsd_open_flag flags, int exclusive_create);
+static int open_existing(const pgsd_comm* on, struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags);
+
 extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fname, const char* application,
                                     const char* schema, uint32_t schema_version,
                                     enum pgsd_open_flag flags, int exclusive_create)
     try
+    {
+    return create_and_open(nullptr, handle, fname, application, schema, schema_version, flags, exclusive_create);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_create_and_open_on(const struct pgsd_comm* comm, struct pgsd_handle* handle, const char* fname,
+                                       const char* application, const char* schema, uint32_t schema_version,
+                                       enum pgsd_open_flag flags, int exclusive_create)
+    try
+    {
+    if (!comm_usable(comm))
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    return create_and_open(comm, handle, fname, application, schema, schema_version, flags, exclusive_create);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_open_on(const struct pgsd_comm* comm, struct pgsd_handle* handle, const char* fname,
+                            enum pgsd_open_flag flags)
+    try
+    {
+    if (!comm_usable(comm))
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    return open_existing(comm, handle, fname, flags);
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_handle_allgather(struct pgsd_handle* handle, const void* send, void* recv, size_t bytes)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !send || !recv)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (s->P == 1)
+        {
+        if (send != recv)
+            memcpy(recv, send, bytes);
+        return PGSD_SUCCESS;
+        }
+    if (s->gather(send, recv, bytes) != 0)
+        {
+        set_last_error("communicator allgather failed");
+        return PGSD_ERROR_COMM;
+        }
+    return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+static int create_and_open(const pgsd_comm* on, struct pgsd_handle* handle, const char* fname, const char* application,
+                           const char* schema, uint32_t schema_version, enum pgsd_open_flag flags, int exclusive_create)
     {
     // pgsd.c:1710-1773
     if (!handle || !fname || !application || !schema)
@@ -1268,7 +1346,7 @@ extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fnam
     handle->fd = -1;
     if (flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
-    Impl* s = new_impl();
+    Impl* s = new_impl(on);
     s->flags = flags;
 
     // rank 0 creates and lays out the file, then everybody opens it
@@ -1306,20 +1384,25 @@ extern "C" int pgsd_create_and_open(struct pgsd_handle* handle, const char* fnam
     publish(handle, s);
     return PGSD_SUCCESS;
     }
+
+extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags)
+    try
+    {
+    return open_existing(nullptr, handle, fname, flags);
+    }
 catch (...)
     {
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags)
-    try
+static int open_existing(const pgsd_comm* on, struct pgsd_handle* handle, const char* fname, enum pgsd_open_flag flags)
     {
     // pgsd.c:1775-1812
     if (!handle || !fname)
         return PGSD_ERROR_INVALID_ARGUMENT;
     memset(handle, 0, sizeof(*handle));
     handle->fd = -1;
-    Impl* s = new_impl();
+    Impl* s = new_impl(on);
     s->flags = flags;
     int rc = PGSD_SUCCESS;
     s->fd = open(fname, flags == PGSD_OPEN_READONLY ? O_RDONLY : O_RDWR);
@@ -1338,10 +1421,6 @@ extern "C" int pgsd_open(struct pgsd_handle* handle, const char* fname, enum pgs
     handle->impl = s;
     publish(handle, s);
     return PGSD_SUCCESS;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
     }
 
 extern "C" int pgsd_close(struct pgsd_handle* handle)

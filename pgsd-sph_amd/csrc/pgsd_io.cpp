@@ -186,6 +186,64 @@ WriterPool* writer_pool_create(unsigned n_threads, const cpu_set_t* cpus)
     return new WriterPool(n_threads, cpus);
     }
 
+// "0-7,64-71" -> the CPUs of the list that are also in `allowed`; returns how many
+static int parse_cpulist(const char* buf, const cpu_set_t* allowed, cpu_set_t* out)
+    {
+    CPU_ZERO(out);
+    int count = 0;
+    for (const char* p = buf; *p;)
+        {
+        char* end;
+        long a = strtol(p, &end, 10);
+        if (end == p)
+            break;
+        long b = a;
+        if (*end == '-')
+            b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, allowed))
+                {
+                CPU_SET((int)c, out);
+                count++;
+                }
+        if (*end != ',')
+            break;
+        p = end + 1;
+        }
+    return count;
+    }
+
+// The CPUs that share a last-level cache with the first CPU of `base` (nullptr: every CPU this process may run
+// on), restricted to `base`: threads pinned inside this set hand cache lines to each other through the L3
+// instead of through DRAM (the warmer / writer pair of the device pipeline).  false when sysfs does not say.
+bool l3_cpus(const cpu_set_t* base, cpu_set_t* out)
+    {
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (base)
+        allowed = *base;
+    else if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+        return false;
+    int first = -1;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &allowed))
+            {
+            first = c;
+            break;
+            }
+    if (first < 0)
+        return false;
+    char path[256], buf[4096];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", first);
+    FILE* f = fopen(path, "r");
+    if (!f)
+        return false;
+    size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return parse_cpulist(buf, &allowed, out) >= 2;
+    }
+
 // CPUs of the NUMA node a PCI device hangs off, intersected with what this process may run on.
 // false when the node is unknown (-1), the machine has one node, or PGSD_NUMA=0.
 bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out)
@@ -218,27 +276,7 @@ bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out)
     CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
         return false;
-    CPU_ZERO(out);
-    int count = 0;
-    for (char* p = buf; *p;)
-        {
-        char* end;
-        long a = strtol(p, &end, 10);
-        if (end == p)
-            break;
-        long b = a;
-        if (*end == '-')
-            b = strtol(end + 1, &end, 10);
-        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
-            if (CPU_ISSET((int)c, &allowed))
-                {
-                CPU_SET((int)c, out);
-                count++;
-                }
-        p = (*end == ',') ? end + 1 : end;
-        if (*end != ',' )
-            break;
-        }
+    const int count = parse_cpulist(buf, &allowed, out);
     int total = CPU_COUNT(&allowed);
     return count > 0 && count < total; // a single node (or all CPUs) needs no pinning
     }

@@ -174,6 +174,12 @@ _sig("pgsd_comm_rank", c_i32)
 _sig("pgsd_comm_size", c_i32)
 _sig("pgsd_comm_allgather", c_i32, c_vp, c_vp, ctypes.c_size_t)
 _sig("pgsd_comm_barrier", c_i32)
+_sig("pgsd_comm_create_shm", c_i32, c_cp, c_i32, c_i32, ctypes.POINTER(Comm))
+_sig("pgsd_comm_create_rccl", c_i32, c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(Comm))
+_sig("pgsd_comm_release", None, ctypes.POINTER(Comm))
+_sig("pgsd_create_and_open_on", c_i32, ctypes.POINTER(Comm), HP, c_cp, c_cp, c_cp, c_u32, c_i32, c_i32)
+_sig("pgsd_open_on", c_i32, ctypes.POINTER(Comm), HP, c_cp, c_i32)
+_sig("pgsd_handle_allgather", c_i32, HP, c_vp, c_vp, ctypes.c_size_t)
 _sig("pgsd_partition_rows", c_i32, c_u64, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64))
 _sig("pgsd_write_chunk_device", c_i32, HP, c_cp, c_i32, c_u64, c_u32, c_u64, c_u32, c_u64, c_u64,
      ctypes.c_bool, c_u8, ctypes.POINTER(FieldDesc))

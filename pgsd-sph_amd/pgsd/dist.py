@@ -130,6 +130,40 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
     return "torch-" + backend
 
 
+def create_shm(name, rank, size):
+    """A shm communicator that is NOT installed as the process default (``pgsd_comm_create_shm``): pass it to
+    ``pgsd.fl.open(..., comm=)``; several ranks may live in one process (one thread each).  Let it go with
+    :func:`release` once every file opened on it is closed."""
+    comm = _lib.Comm()
+    rc = lib.pgsd_comm_create_shm(name.encode(), int(rank), int(size), ctypes.byref(comm))
+    if rc != 0:
+        raise RuntimeError("pgsd_comm_create_shm failed: " + _lib.last_error())
+    return comm
+
+
+def rccl_unique_id():
+    """The 128-byte ncclUniqueId one rank creates and hands to the others (``pgsd_comm_rccl_unique_id``)."""
+    buf = (ctypes.c_uint8 * 128)()
+    if lib.pgsd_comm_rccl_unique_id(buf) != 0:
+        raise RuntimeError("pgsd_comm_rccl_unique_id failed: " + _lib.last_error())
+    return bytes(buf)
+
+
+def create_rccl(unique_id, rank, size, device):
+    """An RCCL communicator (one rank = one GPU; the ranks may be threads of one process) that is not the
+    process default; see :func:`create_shm`."""
+    comm = _lib.Comm()
+    rc = lib.pgsd_comm_create_rccl(bytes(unique_id), int(rank), int(size), int(device), ctypes.byref(comm))
+    if rc != 0:
+        raise RuntimeError("pgsd_comm_create_rccl failed: " + _lib.last_error())
+    return comm
+
+
+def release(comm):
+    """Destroy a communicator made by :func:`create_shm` / :func:`create_rccl` (collective for shm: a barrier)."""
+    lib.pgsd_comm_release(ctypes.byref(comm))
+
+
 def finalize():
     lib.pgsd_comm_finalize()
     _retire()

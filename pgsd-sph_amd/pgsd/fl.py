@@ -109,6 +109,11 @@ class DeviceField(object):
     @classmethod
     def from_tensor(cls, t, out_dtype=None, order=None, bitcast=False, columns=None):
         """Build from a torch GPU tensor of shape (N,), (N, M) or a column slice of (N, S)."""
+        if columns is None and order is None and t.dim() == 2 and t.is_contiguous():
+            # the common case (a whole row-major array), without the general path's dozen tensor queries
+            N, M = t.shape
+            return cls(t.data_ptr(), str(t.dtype)[6:], N, M, stride=max(M, 1), col0=0, out_dtype=out_dtype,
+                       order=None, bitcast=bitcast, keepalive=[t])
         if t.dim() == 1:
             t2 = t.unsqueeze(1)
         elif t.dim() == 2:
@@ -196,21 +201,26 @@ def select_rows(flags):
     return index[:k], k
 
 
-def open(name, mode, application=None, schema=None, schema_version=None):
+def open(name, mode, application=None, schema=None, schema_version=None, comm=None):
     """Open a PGSD file and return a :py:class:`PGSDFile` (fl.pyx:149-228).
 
     Valid modes: ``'r'``, ``'r+'``, ``'w'``, ``'x'``, ``'a'``.  When creating a file
     (``'w'``, ``'x'``, ``'a'`` on a missing file) ``application``, ``schema`` and
     ``schema_version`` are required.
+
+    ``comm`` (not in the reference, whose communicator is always ``MPI_COMM_WORLD``): a communicator made by
+    ``pgsd.dist.create_shm`` / ``create_rccl`` that is NOT the process default -- several ranks in one process
+    (one thread per GPU), each with a file object of its own.  It must outlive the file object.
     """
-    return PGSDFile(str(name), mode, application, schema, schema_version)
+    return PGSDFile(str(name), mode, application, schema, schema_version, comm)
 
 
 class PGSDFile(object):
     """PGSD file access interface (fl.pyx:231-1052)."""
 
-    def __init__(self, name, mode, application, schema, schema_version):
+    def __init__(self, name, mode, application, schema, schema_version, comm=None):
         self.__is_open = False
+        self.__comm = comm
         exclusive_create = 0
         overwrite = 0
         self.__mode = mode
@@ -235,7 +245,7 @@ class PGSDFile(object):
 
         # One process per rank under torchrun: make sure the library knows about the other ranks
         # (a rank that believes it is alone would overwrite its neighbours' rows).
-        if lib.pgsd_comm_size() == 1 and _lib._torch is not None:
+        if comm is None and lib.pgsd_comm_size() == 1 and _lib._torch is not None:
             tdist = _lib._torch.distributed
             if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
                 from . import dist as _dist
@@ -245,6 +255,7 @@ class PGSDFile(object):
         self.__handle = _lib.Handle()
         self.__keepalive = []
         self.__explicit_stream = False
+        self.__source_stream = -1       # what the pipeline was last told (-1: nothing yet)
         self.__async_keep = []
 
         if overwrite:
@@ -258,14 +269,16 @@ class PGSDFile(object):
                         + ', application: ' + application + ', schema: ' + schema
                         + ', and schema_version: ' + str(schema_version))
             ctypes.set_errno(0)
-            retval = lib.pgsd_create_and_open(ctypes.byref(self.__handle), name.encode('utf-8'),
-                                              application.encode('utf-8'), schema.encode('utf-8'),
-                                              lib.pgsd_make_version(schema_version[0], schema_version[1]),
-                                              c_flags, exclusive_create)
+            args = (ctypes.byref(self.__handle), name.encode('utf-8'),
+                    application.encode('utf-8'), schema.encode('utf-8'),
+                    lib.pgsd_make_version(schema_version[0], schema_version[1]), c_flags, exclusive_create)
+            retval = lib.pgsd_create_and_open(*args) if comm is None \
+                else lib.pgsd_create_and_open_on(ctypes.byref(comm), *args)
         else:
             logger.info('opening file: ' + name + ' with mode: ' + mode)
             ctypes.set_errno(0)
-            retval = lib.pgsd_open(ctypes.byref(self.__handle), name.encode('utf-8'), c_flags)
+            args = (ctypes.byref(self.__handle), name.encode('utf-8'), c_flags)
+            retval = lib.pgsd_open(*args) if comm is None else lib.pgsd_open_on(ctypes.byref(comm), *args)
         _raise_on_error(retval, name)
         self.__is_open = True
 
@@ -429,10 +442,21 @@ class PGSDFile(object):
         return int(offset.sum()), M * int(offset[0:rank].sum())
 
     def _sync_source_stream(self):
-        """Tell the pipeline which stream produced the arrays: PyTorch's current stream."""
-        if _lib._torch is not None and _lib._torch.cuda.is_available():
-            stream = _lib._torch.cuda.current_stream().cuda_stream
+        """Tell the pipeline which stream produced the arrays: PyTorch's current stream.  (The raw-handle
+        query and the remembered last value keep this at ~1 us per call: `torch.cuda.current_stream()` builds
+        a Stream object, 10-15 us, once per device write of a small frame.)"""
+        torch = _lib._torch
+        if torch is None:
+            return
+        try:
+            stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+        except AttributeError:  # pragma: no cover - other torch versions
+            if not torch.cuda.is_available():
+                return
+            stream = torch.cuda.current_stream().cuda_stream
+        if stream != self.__source_stream:
             _raise_on_error(lib.pgsd_device_set_source_stream(self._h(), ctypes.c_void_p(stream)), self.__name)
+            self.__source_stream = stream
 
     def set_source_stream(self, stream):
         """Name the HIP stream (integer handle) on which the particle arrays are produced;
@@ -440,6 +464,7 @@ class PGSDFile(object):
         self._check_open()
         _raise_on_error(lib.pgsd_device_set_source_stream(self._h(), ctypes.c_void_p(stream)), self.__name)
         self.__explicit_stream = True
+        self.__source_stream = stream
 
     def _write_chunk_device(self, name, data, offset, rank, write_all):
         if not self.__explicit_stream:
@@ -501,6 +526,7 @@ class PGSDFile(object):
         self._check_open()
         cfg = _lib.DeviceConfig(device, slab_bytes, n_slabs, n_writers, 1 if profile else 0, 0)
         _raise_on_error(lib.pgsd_device_configure(self._h(), ctypes.byref(cfg)), self.__name)
+        self.__source_stream = -1       # a new pipeline: it has to be told again
 
     def device_stats(self, reset=False):
         """dict of pipeline counters (pack launches/ms/bytes, D2H and write bytes/ms)."""
@@ -678,6 +704,27 @@ class PGSDFile(object):
     @property
     def application(self):
         return self.__handle.header.application.decode('utf-8')
+
+    @property
+    def rank(self):
+        """int: this process's (or thread's) rank in the communicator the file was opened on."""
+        return int(self.__handle.rank)
+
+    @property
+    def nprocs(self):
+        """int: number of ranks of the communicator the file was opened on."""
+        return int(self.__handle.nprocs)
+
+    def allgather(self, send):
+        """Allgather the bytes of the 1-D uint8 array ``send`` over the file's communicator
+        (``pgsd_handle_allgather``); returns a ``(nprocs, len(send))`` uint8 array."""
+        self._check_open()
+        send = numpy.ascontiguousarray(send, dtype=numpy.uint8)
+        out = numpy.zeros((self.nprocs, send.size), dtype=numpy.uint8)
+        retval = lib.pgsd_handle_allgather(self._h(), send.ctypes.data_as(ctypes.c_void_p),
+                                           out.ctypes.data_as(ctypes.c_void_p), send.size)
+        _raise_on_error(retval, self.__name)
+        return out
 
     @property
     def nframes(self):

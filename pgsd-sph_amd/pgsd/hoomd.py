@@ -322,8 +322,11 @@ class HOOMDTrajectory(object):
 
     # ------------------------------------------------------------------ writing
     def _comm(self):
-        from ._lib import lib
-        return lib.pgsd_comm_rank(), lib.pgsd_comm_size()
+        # the communicator the FILE was opened on (the process default unless `fl.open(..., comm=)` chose another)
+        f = self.file
+        if hasattr(f, 'nprocs'):
+            return f.rank, f.nprocs
+        return 0, 1                     # pgsd.pypgsd.PGSDFile: the pure-Python reader, one rank
 
     def append(self, frame, wait=True):
         """Append a frame (collective over the ranks of the installed communicator).
@@ -394,10 +397,13 @@ class HOOMDTrajectory(object):
             names = list(container._default_value)
             if path == 'particles':
                 names += list(container._extra_default_value)
+            values = container.__dict__
             for name in names:
                 if (path, name) == ('particles', 'N'):
                     # None = "as in frame 0": no count chunk; decided below from the global count otherwise
                     plan.append((path, name, frame.particles.N is not None))
+                elif values.get(name, values.get('_' + name)) is None:
+                    plan.append((path, name, False))        # most of the schema, most of the time: not set
                 else:
                     plan.append((path, name, self._should_write(path, name, frame, None)))
         n_local = int(frame.particles.N) if frame.particles.N is not None else 0
@@ -408,17 +414,10 @@ class HOOMDTrajectory(object):
         else:
             part_dist = numpy.array([n_local], dtype=numpy.uint64)
         if size > 1:
-            from ._lib import lib
-            import ctypes
             mine = numpy.zeros(8 + len(plan), dtype=numpy.uint8)
             mine[:8] = numpy.array([n_local], dtype=numpy.uint64).view(numpy.uint8)
             mine[8:] = [1 if w else 0 for _, _, w in plan]
-            allb = numpy.zeros(size * len(mine), dtype=numpy.uint8)
-            rc = lib.pgsd_comm_allgather(mine.ctypes.data_as(ctypes.c_void_p), allb.ctypes.data_as(ctypes.c_void_p),
-                                         len(mine))
-            if rc != 0:
-                raise RuntimeError("communicator allgather failed")
-            allb = allb.reshape(size, len(mine))
+            allb = self.file.allgather(mine)
             if frame.part_dist is None:
                 part_dist = numpy.ascontiguousarray(allb[:, :8]).view(numpy.uint64).reshape(size)
             agreed = allb[:, 8:].max(axis=0)

@@ -86,3 +86,19 @@ def test_a_dead_peer_is_an_error_not_a_hang():
             os.unlink("/dev/shm/" + name)
         except OSError:
             pass
+
+
+def test_eight_ranks_as_threads_of_one_process_on_per_handle_communicators(tmp_path):
+    """`pgsd_comm_create_shm` + `pgsd_create_and_open_on`: communicators that are not the process default, one per
+    thread, eight ranks in ONE process writing config 3's chunk sequence from host arrays -- the file is the
+    reference-written golden posvelid.p8.gsd (the GPU twin of this test: tests/test_gpu_eight_ranks.py)."""
+    import subprocess
+    import sys
+    import scenario as S
+    mine = str(tmp_path / "p8.gsd")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "thread_ranks_worker.py")
+    p = subprocess.run([sys.executable, worker, "shm", "8", mine, "posvelid", "host"], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-3000:])
+    with open(mine, "rb") as a, open(os.path.join(S.GOLDEN, "posvelid.p8.gsd"), "rb") as b:
+        assert a.read() == b.read()

@@ -317,3 +317,34 @@ def test_arrays_larger_than_4_GiB():
     assert _lib.lib.pgsd_unpack_fields(2, jobs, N, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(back.view(torch.int32), src.view(torch.int32))
+
+
+@pytest.mark.parametrize("layout", ["float4_idw", "float4_separate_id", "double4_separate_id"])
+def test_config2_one_mebi_rows_position_velocity_id(layout):
+    """BASELINE config 2 at its own size: 2^20 particles, position + velocity + id packed by one launch,
+    bit-exact against `oracle_pack_rows` -- HOOMD float4 arrays with the id in position.w, float4 arrays with
+    the id in its own uint32 array (SURVEY 8(d)'s sketch), and the double4 -> float32 conversion variant.
+    Values as SURVEY 8(d) prescribes: pos = U(-L/2, L/2), L = 100; vel = N(0, 1); id = a permutation; seed 1234.
+    (Runs through both kernel families: the autouse fixture of this file.)"""
+    N = 1 << 20
+    rng = np.random.default_rng(1234)
+    ft = np.float64 if layout.startswith("double4") else np.float32
+    pos = ((rng.random((N, 4)) - 0.5) * 100.0).astype(ft)
+    vel = rng.standard_normal((N, 4)).astype(ft)
+    ids = rng.permutation(N).astype(np.uint32)
+    if layout == "float4_idw":
+        pos[:, 3] = ids.view(np.float32)
+    dpos, dvel = dev(pos), dev(vel)
+    dids = dev(ids.view(np.int32).reshape(N, 1))
+    o_pos, o_vel, o_id = empty_out(N, 3, np.float32), empty_out(N, 3, np.float32), empty_out(N, 1, np.uint32)
+    id_job = (o_id, np.uint32, 1, dpos, 3, None, True) if layout == "float4_idw" else \
+        (o_id, np.uint32, 1, dids.view(torch.int32), 0, None, False)
+    G.hip_pack([(o_pos, np.float32, 3, dpos, 0, None, False), (o_vel, np.float32, 3, dvel, 0, None, False), id_job], N)
+    check(o_pos, G.oracle_pack(pos, 3, out_dtype=np.float32))
+    check(o_vel, G.oracle_pack(vel, 3, out_dtype=np.float32))
+    if layout == "float4_idw":
+        check(o_id, G.oracle_pack(pos, 1, col0=3, out_dtype=np.uint32, bitcast=True))
+    else:
+        check(o_id, G.oracle_pack(ids.view(np.int32).reshape(N, 1), 1, out_dtype=np.uint32))
+    assert (o_id.cpu().numpy()[:4 * N].view(np.uint32) == ids).all()
+    assert int(o_id.cpu().numpy()[:4 * N].view(np.uint32).astype(np.int64).sum()) == N * (N - 1) // 2
