@@ -480,7 +480,11 @@ extern "C"
          dst[(order ? order[i] : i) * dst_stride + dst_col0 + c] = convert(chunk[row_offset + i][c])
        converted from the chunk's type to dst_type (same rules as the pack direction; bitcast
        needs equal element sizes).  Columns of the destination rows that no chunk writes are
-       left untouched, so position.xyz and the type id can be restored into one Scalar4 array. */
+       left untouched, so position.xyz and the type id can be restored into one Scalar4 array --
+       unless fill_rest is set: then every column of the row that no chunk of the same launch
+       (pgsd_unpack_fields call / pgsd_device_wait_read) writes receives fill_bits, the bit pattern of
+       one destination element.  Velocity without a mass chunk thus restores as {vx, vy, vz, 1.0f}:
+       ONE whole 16-byte row per particle instead of a 12-byte piece at a 16-byte stride. */
     struct pgsd_field_dst
         {
         void* dst;             /* device pointer */
@@ -489,6 +493,9 @@ extern "C"
         uint32_t dst_stride;   /* elements per destination row */
         uint32_t dst_col0;     /* first destination column */
         uint32_t bitcast;
+        uint32_t fill_rest;    /* 1: columns of the row no chunk of the launch writes are set to fill_bits */
+        uint32_t reserved;
+        uint64_t fill_bits;    /* low sizeof(dst_type) bytes = one destination element */
         };
 
     /* Device twin of pgsd_read_chunk (reference pgsd.h:604-610) for a row slab: rows

@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -321,21 +322,7 @@ class DevicePipeline
             }
         for (uint32_t i = 0; i < m_slabs_ready; i++)
             m_free_slabs.push_back(i);
-        // EXPERIMENT (PGSD_WARMERS=n): a slab the SDMA engine has just filled is cold for the CPU -- every line
-        // comes from DRAM while the writer's pwrite copies it into the page cache (6-7 GB/s), whereas the same
-        // pwrite from cache-warm memory runs at 12-15 GB/s (the host path on an L3-resident array).  n warmer
-        // threads on cores that share the writer's L3 read each landed piece once before it is handed on.
-        unsigned warmers = 0;
-        if (const char* v = getenv("PGSD_WARMERS"))
-            warmers = (unsigned)(atoi(v) > 0 ? atoi(v) : 0);
         const cpu_set_t* pin = m_numa ? &m_numa_cpus : nullptr;
-        if (warmers)
-            {
-            m_l3 = l3_cpus(pin, &m_l3_cpus);
-            if (m_l3)
-                pin = &m_l3_cpus;
-            m_warm_pool = writer_pool_create(warmers, pin);
-            }
         m_pool = writer_pool_create(m_cfg.n_writers, pin);
         m_dispatcher = std::thread([this] { dispatch_loop(); });
         if (pin)
@@ -365,8 +352,6 @@ class DevicePipeline
                 }
             ReadEngine::release(m_reader);
             }
-        if (m_warm_pool)
-            writer_pool_destroy(m_warm_pool); // joins the warmers (they feed the writers)
         if (m_pool)
             writer_pool_destroy(m_pool); // joins the writers
         (void)hipSetDevice(m_cfg.device);
@@ -752,8 +737,8 @@ class DevicePipeline
             }
         (void)hipSetDevice(m_cfg.device);
         hipError_t e = hipStreamSynchronize(m_pack_stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(m_copy_stream);
+        if (e == hipSuccess && m_copy_used.exchange(false))
+            e = hipStreamSynchronize(m_copy_stream); // (a frame of direct chunks never touched it)
         if (e != hipSuccess)
             fail(std::string("stream synchronize: ") + hipGetErrorString(e));
         else
@@ -1142,6 +1127,7 @@ class DevicePipeline
                     }
                 Slab& s = m_slabs[(size_t)si];
                 TraceRange tr("pgsd:d2h_enqueue file_off=%llu bytes=%llu", (unsigned long long)(job.file_offset + (long long)off), n);
+                m_copy_used.store(true);
                 hipError_t e = hipMemcpyAsync(s.host, job.dsrc + off, n, hipMemcpyDeviceToHost, m_copy_stream);
                 if (e == hipSuccess)
                     e = hipEventRecord(s.copied, m_copy_stream);
@@ -1154,10 +1140,7 @@ class DevicePipeline
                     continue;
                     }
                 long long foff = job.file_offset + (long long)off;
-                if (m_warm_pool)
-                    writer_pool_submit(m_warm_pool, [this, si, n, foff] { warm_piece(si, n, foff); });
-                else
-                    writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
+                writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
                 }
             if (c0 && c1)
                 {
@@ -1266,6 +1249,7 @@ class DevicePipeline
             if (ok)
                 {
                 ReadEngine::Slab& s = reader->slabs[(size_t)si];
+                m_copy_used.store(true);
                 hipError_t e = hipMemcpyAsync(dst, s.host, n, hipMemcpyHostToDevice, m_copy_stream);
                 if (e == hipSuccess)
                     e = hipEventRecord(s.copied, m_copy_stream);
@@ -1298,29 +1282,6 @@ class DevicePipeline
         // Last touch of the pipeline by this piece: the destructor (and wait_read) wait for the count
         // of PIECES to reach zero, so no straggler of a finished chunk is left behind.
         read_done();
-        }
-
-    // warmer thread: wait for the piece to land, read every cache line of it once (into the L3 this thread
-    // shares with the writer), hand it to the writer
-    void warm_piece(int si, size_t n, long long foff)
-        {
-        (void)hipSetDevice(m_cfg.device);
-        Slab& s = m_slabs[(size_t)si];
-        if (hipEventSynchronize(s.copied) == hipSuccess)
-            {
-            TraceRange tr("pgsd:warm file_off=%llu bytes=%llu", (unsigned long long)foff, n);
-            const volatile uint64_t* p = (const volatile uint64_t*)s.host;
-            uint64_t acc = 0;
-            const size_t words = n / 8;
-            // four independent streams a page apart keep more misses in flight than one sequential walk
-            const size_t q = (words / 4) & ~(size_t)7;
-            for (size_t i = 0; i < q; i += 8)
-                acc += p[i] + p[q + i] + p[2 * q + i] + p[3 * q + i];
-            for (size_t i = 4 * q; i < words; i += 8)
-                acc += p[i];
-            m_warm_sink += acc;
-            }
-        writer_pool_submit(m_pool, [this, si, n, foff] { write_piece(si, n, foff); });
         }
 
     void write_piece(int si, size_t n, long long foff)
@@ -1391,11 +1352,8 @@ class DevicePipeline
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
     hipEvent_t m_direct_packed = nullptr;  // pack event of the newest of them
     WriterPool* m_pool = nullptr;
-    WriterPool* m_warm_pool = nullptr; // PGSD_WARMERS experiment
-    bool m_l3 = false;
-    cpu_set_t m_l3_cpus;
-    volatile uint64_t m_warm_sink = 0;
     ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device
+    std::atomic<bool> m_copy_used {false}; // something was enqueued on the copy stream since drain() last synchronised it
     std::mutex m_copy_mutex; // serialises enqueues on the copy / pack streams from reader threads
     size_t m_reads_outstanding = 0;
     std::vector<std::shared_ptr<ReadReq>> m_unpack_pending; // guarded by m_copy_mutex

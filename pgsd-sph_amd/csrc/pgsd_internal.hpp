@@ -78,7 +78,6 @@ inline int comm_barrier(const pgsd_comm& c)
 class WriterPool;
 WriterPool* writer_pool_create(unsigned n_threads, const cpu_set_t* cpus = nullptr);
 bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out);
-bool l3_cpus(const cpu_set_t* base, cpu_set_t* out);
 void writer_pool_destroy(WriterPool*);
 void writer_pool_submit(WriterPool*, std::function<void()> fn);
 // Write [buf, buf+bytes) at `offset` of fd, split over the pool; blocks until done.

@@ -213,37 +213,6 @@ static int parse_cpulist(const char* buf, const cpu_set_t* allowed, cpu_set_t* o
     return count;
     }
 
-// The CPUs that share a last-level cache with the first CPU of `base` (nullptr: every CPU this process may run
-// on), restricted to `base`: threads pinned inside this set hand cache lines to each other through the L3
-// instead of through DRAM (the warmer / writer pair of the device pipeline).  false when sysfs does not say.
-bool l3_cpus(const cpu_set_t* base, cpu_set_t* out)
-    {
-    cpu_set_t allowed;
-    CPU_ZERO(&allowed);
-    if (base)
-        allowed = *base;
-    else if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
-        return false;
-    int first = -1;
-    for (int c = 0; c < CPU_SETSIZE; c++)
-        if (CPU_ISSET(c, &allowed))
-            {
-            first = c;
-            break;
-            }
-    if (first < 0)
-        return false;
-    char path[256], buf[4096];
-    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", first);
-    FILE* f = fopen(path, "r");
-    if (!f)
-        return false;
-    size_t n = fread(buf, 1, sizeof(buf) - 1, f);
-    fclose(f);
-    buf[n] = 0;
-    return parse_cpulist(buf, &allowed, out) >= 2;
-    }
-
 // CPUs of the NUMA node a PCI device hangs off, intersected with what this process may run on.
 // false when the node is unknown (-1), the machine has one node, or PGSD_NUMA=0.
 bool numa_cpus_of_pci_device(const char* pci_bus_id, cpu_set_t* out)

@@ -947,6 +947,46 @@ __device__ __forceinline__ void unrows_load(const uint32_t* p, uint32_t nw, uint
     w[0] = r.lo.x, w[1] = r.lo.y, w[2] = r.lo.z, w[3] = r.lo.w;
     }
 
+// One WHOLE destination row: column e takes v[e] (f32 / 32-bit bits from a chunk) unless bit e of fillmask is
+// set, then the fill element.  Compile-time loops only (a run-time index into c[] would go to scratch).
+template<bool F64>
+__device__ __forceinline__ void unrows_store_whole(uint32_t* drow, const uint32_t (&v)[4], uint32_t fillmask, uint32_t fill_lo,
+                                                   uint32_t fill_hi)
+    {
+    if constexpr (!F64)
+        {
+        uint32_t c[ROWS_MAX_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++)
+            c[e] = ((fillmask >> e) & 1u) ? fill_lo : v[e];
+        row_store<4>(drow, c, 4);
+        }
+    else
+        {
+        uint32_t c[ROWS_MAX_WORDS];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++)
+            {
+            const uint64_t bits = (uint64_t)__double_as_longlong((double)__uint_as_float(v[e]));
+            const bool f = (fillmask >> e) & 1u;
+            c[2 * e] = f ? fill_lo : (uint32_t)bits;
+            c[2 * e + 1] = f ? fill_hi : (uint32_t)(bits >> 32);
+            }
+        row_store<8>(drow, c, 8);
+        }
+    }
+
+// v[col0 + s] = w[s] for s < nw, without run-time indexing
+__device__ __forceinline__ void unrows_place(uint32_t (&v)[4], const uint32_t (&w)[4], uint32_t nw, uint32_t col0)
+    {
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++)
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            if (s < nw && col0 + s == e)
+                v[e] = w[s];
+    }
+
 template<int T, int U, bool F64> __global__ __launch_bounds__(T) void unpack_rows_kernel(const UnrowsArgs args)
     {
     const UnrowsGroup& g = args.g[blockIdx.y];
@@ -971,6 +1011,59 @@ template<int T, int U, bool F64> __global__ __launch_bounds__(T) void unpack_row
     uint32_t* dst = (uint32_t*)g.dst;
     const uint32_t* a = (const uint32_t*)g.a;
     const uint32_t* b = (const uint32_t*)g.b;
+    if (g.a_nw == 3 && g.a_col0 == 0 && b == nullptr && g.fill_on)
+        {
+        // xyz from a chunk, w = a constant (velocity without a mass chunk -> {vx, vy, vz, 1.0f}): whole rows out
+        u32x3 xyz[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * T;
+            if (i < N)
+                xyz[k] = __builtin_nontemporal_load((const u32x3_a4*)(a + i * 3));
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * T;
+            if (i < N)
+                {
+                const uint32_t c[4] = {xyz[k].x, xyz[k].y, xyz[k].z, 0};
+                unrows_store_whole<F64>(dst + i * DW, c, 8u, g.fill_lo, g.fill_hi);
+                }
+            }
+        return;
+        }
+    if (g.fill_on)
+        {
+        // any other one- or two-chunk shape with a fill: compose the whole row, one store
+        uint32_t mask = 15u;
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            {
+            if (s < g.a_nw)
+                mask &= ~(1u << (g.a_col0 + s));
+            if (b != nullptr && s < g.b_nw)
+                mask &= ~(1u << (g.b_col0 + s));
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * T;
+            if (i >= N)
+                continue;
+            uint32_t wa[4], wb[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+            unrows_load(a + i * g.a_nw, g.a_nw, wa);
+            unrows_place(v, wa, g.a_nw, g.a_col0);
+            if (b != nullptr)
+                {
+                unrows_load(b + i * g.b_nw, g.b_nw, wb);
+                unrows_place(v, wb, g.b_nw, g.b_col0);
+                }
+            unrows_store_whole<F64>(dst + i * DW, v, mask, g.fill_lo, g.fill_hi);
+            }
+        return;
+        }
     if (g.a_nw == 3 && g.a_col0 == 0 && b != nullptr && g.b_nw == 1 && g.b_col0 == 3)
         {
         // the hot shape: xyz from one chunk, w from another, whole rows out
@@ -1012,6 +1105,28 @@ template<int T, int U, bool F64> __global__ __launch_bounds__(T) void unpack_row
         unrows_store<F64>(dst + i * DW, wa, g.a_nw, g.a_col0);
         if (b != nullptr)
             unrows_store<F64>(dst + i * DW, wb, g.b_nw, g.b_col0);
+        }
+    }
+
+// ------------------------------------------------------------------ fill of untouched columns (generic paths)
+// pgsd_field_dst.fill_rest where the launch does not assemble whole rows (scatter index, narrow or wide
+// elements, more than two chunks per array): the columns in colmask of every destination row receive the fill
+// element before the chunks' kernels run.  Element per lane: a fallback, not a hot path.
+__global__ __launch_bounds__(256) void fill_cols_kernel(const FillArgs a)
+    {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = t / a.stride;
+    const uint32_t col = (uint32_t)(t % a.stride);
+    if (row >= a.N || col >= 32 || !((a.colmask >> col) & 1u))
+        return;
+    const uint64_t r = a.order ? (uint64_t)a.order[row] : row;
+    char* p = (char*)a.dst + (r * a.stride + col) * a.dsz;
+    switch (a.dsz)
+        {
+        case 1: *(uint8_t*)p = (uint8_t)a.bits; break;
+        case 2: *(uint16_t*)p = (uint16_t)a.bits; break;
+        case 4: *(uint32_t*)p = (uint32_t)a.bits; break;
+        default: *(uint64_t*)p = a.bits; break;
         }
     }
 
@@ -1772,6 +1887,7 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
             ok = ok && ssz == dsz;
         else
             ok = ok && !(!s_int && d_int) && !(s_int && !d_int && ssz == 8);
+        ok = ok && !(q.dst.fill_rest && q.dst.dst_stride > 32); // the fill addresses columns with a 32-bit mask
         if (!ok)
             {
             if (err)
@@ -1791,6 +1907,8 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
         j.dst_col0 = q.dst.dst_col0;
         j.magic = q.M == 1 ? 0u : (uint32_t)(((1ull << 32) + q.M - 1) / q.M);
         j.rowbytes = q.M * ssz;
+        j.fill_rest = q.dst.fill_rest ? 1u : 0u;
+        j.fill_bits = q.dst.fill_bits;
         all.push_back(j);
         }
     // chunks of one destination array next to each other (their relative order is kept)
@@ -1844,6 +1962,13 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
                         UnrowsGroup& g = plan.args.g[plan.args.n_groups++];
                         g.dst = j0.dst;
                         g.a = j0.src;
+                        for (size_t k = i; k < e && !dense; k++)
+                            if (all[k].fill_rest && !g.fill_on)
+                                {
+                                g.fill_on = 1;
+                                g.fill_lo = (uint32_t)all[k].fill_bits;
+                                g.fill_hi = (uint32_t)(all[k].fill_bits >> 32);
+                                }
                         if (dense)
                             {
                             const uint64_t bytes = N * (uint64_t)j0.M * j0.ssz;
@@ -1880,6 +2005,41 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
             if (!taken[i])
                 rest.push_back(all[i]);
         all.swap(rest);
+        }
+    // fills the remaining (tiled / generic) chunks asked for: one pass per destination array over the columns
+    // none of ITS chunks writes, ahead of the chunks on the stream
+    for (size_t i = 0; i < all.size();)
+        {
+        size_t e = i;
+        while (e < all.size() && all[e].dst == all[i].dst)
+            e++;
+        uint32_t covered = 0;
+        const UnpackJob* want = nullptr;
+        for (size_t k = i; k < e; k++)
+            {
+            for (uint32_t c = 0; c < all[k].M && all[k].dst_col0 + c < 32; c++)
+                covered |= 1u << (all[k].dst_col0 + c);
+            if (all[k].fill_rest && !want)
+                want = &all[k];
+            }
+        if (want && want->dst_stride <= 32)
+            {
+            FillArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.dst = want->dst;
+            fa.order = want->order;
+            fa.N = N;
+            fa.bits = want->fill_bits;
+            fa.stride = want->dst_stride;
+            fa.dsz = want->dsz;
+            fa.colmask = ~covered & (want->dst_stride >= 32 ? 0xffffffffu : ((1u << want->dst_stride) - 1u));
+            if (fa.colmask)
+                {
+                const uint64_t lanes = N * (uint64_t)fa.stride;
+                hipLaunchKernelGGL(fill_cols_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, fa);
+                }
+            }
+        i = e;
         }
     std::vector<UnpackJob> batch;
     uint32_t sum_rowbytes = 0;

@@ -117,6 +117,17 @@ struct RowsArgs
     };
 static_assert(sizeof(RowsArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
+// columns of destination rows that no chunk of a launch writes, set to one element value
+// (pgsd_field_dst.fill_rest on the paths that do not assemble whole rows)
+struct FillArgs
+    {
+    void* dst;
+    const uint32_t* order;
+    uint64_t N;
+    uint64_t bits;
+    uint32_t stride, dsz, colmask, pad;
+    };
+
 struct PackGenericArgs
     {
     void* dst;
@@ -144,6 +155,9 @@ struct UnpackJob
     uint32_t dst_stride, dst_col0, magic, rowbytes; // rowbytes = M * ssz
     uint32_t lds_off;      // where this chunk's tile sits in the workgroup's LDS
     uint32_t in_group;     // 1: written by the row assembly of its destination array
+    uint32_t fill_rest;    // host side only: the job asked for the untouched columns to be filled ...
+    uint32_t pad;
+    uint64_t fill_bits;    // ... with this element
     };
 
 // A destination array every column of which is restored by chunks of the same launch (position.xyz
@@ -180,7 +194,8 @@ struct UnrowsGroup
     uint32_t a_nw, a_col0, b_nw, b_col0; // dwords per chunk row / first destination ELEMENT
     uint64_t copy_vecs; // dense same-type array riding along: 16-byte vectors to copy from `a` to `dst` (0 = row mode)
     uint32_t copy_tail;
-    uint32_t pad;
+    uint32_t fill_on;   // 1: columns no chunk feeds take the fill element, the row is stored whole
+    uint32_t fill_lo, fill_hi; // bits of one destination element (hi: the upper half of a double)
     };
 
 struct UnrowsArgs

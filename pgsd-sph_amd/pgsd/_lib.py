@@ -97,7 +97,8 @@ class PackJob(ctypes.Structure):
 
 class FieldDst(ctypes.Structure):
     _fields_ = [("dst", c_vp), ("order", c_vp), ("dst_type", c_u32), ("dst_stride", c_u32),
-                ("dst_col0", c_u32), ("bitcast", c_u32)]
+                ("dst_col0", c_u32), ("bitcast", c_u32), ("fill_rest", c_u32), ("reserved", c_u32),
+                ("fill_bits", c_u64)]
 
 
 class UnpackJob(ctypes.Structure):

@@ -29,6 +29,7 @@ _NP_TO_PGSD = {
     numpy.dtype('float32'): _lib.TYPE_FLOAT, numpy.dtype('float64'): _lib.TYPE_DOUBLE,
 }
 _PGSD_TO_NP = {v: k for k, v in _NP_TO_PGSD.items()}
+_TORCH_HAS_GPU = None       # torch.cuda.is_available(), asked once
 
 
 def _pgsd_type(dtype, name=''):
@@ -445,14 +446,17 @@ class PGSDFile(object):
         """Tell the pipeline which stream produced the arrays: PyTorch's current stream.  (The raw-handle
         query and the remembered last value keep this at ~1 us per call: `torch.cuda.current_stream()` builds
         a Stream object, 10-15 us, once per device write of a small frame.)"""
+        global _TORCH_HAS_GPU
         torch = _lib._torch
         if torch is None:
             return
+        if _TORCH_HAS_GPU is None:
+            _TORCH_HAS_GPU = bool(torch.cuda.is_available())
+        if not _TORCH_HAS_GPU:
+            return                      # the device call itself reports the missing GPU
         try:
             stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
         except AttributeError:  # pragma: no cover - other torch versions
-            if not torch.cuda.is_available():
-                return
             stream = torch.cuda.current_stream().cuda_stream
         if stream != self.__source_stream:
             _raise_on_error(lib.pgsd_device_set_source_stream(self._h(), ctypes.c_void_p(stream)), self.__name)
@@ -569,7 +573,7 @@ class PGSDFile(object):
         return data_array
 
     def read_chunk_device(self, frame, name, out=None, N=None, offset=0, columns=None, order=None,
-                          bitcast=False, wait=True):
+                          bitcast=False, wait=True, fill=None):
         """Read rows ``[offset, offset + N)`` of a chunk straight into GPU memory.
 
         The rows are ``pread`` into pinned slabs, copied to HBM and unpacked by a HIP kernel
@@ -587,6 +591,9 @@ class PGSDFile(object):
             order: optional int32 GPU tensor; row ``i`` goes to ``out[order[i]]``.
             bitcast (bool): reinterpret equal-sized elements (uint32 type id -> float ``w`` slot).
             wait (bool): block until the data is in ``out`` (else call :meth:`wait_read`).
+            fill: value for the columns of ``out``'s rows that no chunk read before the same :meth:`wait_read`
+                writes (``pgsd_field_dst.fill_rest``): velocity into a ``Scalar4`` array with ``fill=1.0`` gives
+                ``(vx, vy, vz, 1.0)`` rows, stored whole.  ``None``: those columns keep what they hold.
 
         Returns:
             the destination tensor.
@@ -628,6 +635,10 @@ class PGSDFile(object):
         dst.dst_stride = stride
         dst.dst_col0 = c0
         dst.bitcast = 1 if bitcast else 0
+        if fill is not None:
+            np_out = numpy.dtype(str(t2.dtype)[6:])
+            dst.fill_rest = 1
+            dst.fill_bits = int(numpy.array([fill], dtype=np_out).view(numpy.dtype('u%d' % np_out.itemsize))[0])
         self.__keepalive.append((out, order))
         if not self.__explicit_stream:
             self._sync_source_stream()      # the unpack is ordered behind this stream's use of `out`

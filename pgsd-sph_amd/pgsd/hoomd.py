@@ -710,17 +710,23 @@ class HOOMDTrajectory(object):
                 row = torch.as_tensor(numpy.array(default)).to('cuda')      # (a writable copy: torch refuses read-only views)
                 setattr(snap.particles, name, row.expand(n, M) if M > 1 else row.expand(n))
         if scalar4 and n >= 0:
-            pos4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
-            vel4 = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
-            for chunk, arr, cols, bc in (('particles/position', pos4, (0, 3), False),
-                                         ('particles/typeid', pos4, (3, 4), True),
-                                         ('particles/velocity', vel4, (0, 3), False),
-                                         ('particles/mass', vel4, (3, 4), False)):
-                fr = frame_of(chunk)
-                if fr is not None:
-                    f.read_chunk_device(fr, chunk, out=arr, N=n, offset=row0, columns=cols, bitcast=bc, wait=False)
-                elif chunk == 'particles/mass':
-                    vel4[:, 3] = 1.0
+            # HOOMD's Scalar4 arrays, every row stored WHOLE by the unpack launch: the columns a missing chunk
+            # would have fed come from the `fill` of the chunk that is there (type id 0 as bits, mass 1.0,
+            # position / velocity 0) -- no memset of the arrays, no 12-byte stores at a 16-byte stride
+            pos4 = torch.empty((n, 4), dtype=torch.float32, device='cuda')
+            vel4 = torch.empty((n, 4), dtype=torch.float32, device='cuda')
+            for arr, xyz, w, w_bitcast, w_default in ((pos4, 'particles/position', 'particles/typeid', True, 0.0),
+                                                      (vel4, 'particles/velocity', 'particles/mass', False, 1.0)):
+                f_xyz, f_w = frame_of(xyz), frame_of(w)
+                if f_xyz is not None:
+                    f.read_chunk_device(f_xyz, xyz, out=arr, N=n, offset=row0, columns=(0, 3), wait=False,
+                                        fill=w_default if f_w is None else None)
+                if f_w is not None:
+                    f.read_chunk_device(f_w, w, out=arr, N=n, offset=row0, columns=(3, 4), bitcast=w_bitcast, wait=False,
+                                        fill=0.0 if f_xyz is None else None)
+                if f_xyz is None and f_w is None:
+                    arr.zero_()
+                    arr[:, 3] = w_default
             snap.particles.pos4, snap.particles.vel4 = pos4, vel4
         f.wait_read()
         for log in f.find_matching_chunk_names('log/', False):

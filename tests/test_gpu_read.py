@@ -367,3 +367,99 @@ def test_device_reads_reproduce_the_references_own_read_hashes(P):
         checked += 1
     f.close()
     assert checked >= 10
+
+
+def unpack_filled(specs, N, keep):
+    """like unpack_many, specs carry a fill value: (src_np, dst_tensor, M, col0, order, bitcast, fill or None)"""
+    from pgsd import _lib
+    jobs = (_lib.UnpackJob * len(specs))()
+    for i, (src_np, dst_t, M, col0, order, bitcast, fill) in enumerate(specs):
+        src = dev(src_np.view(np.uint8).reshape(-1))
+        keep.append(src)
+        jobs[i].src = src.data_ptr()
+        jobs[i].src_type = G.type_id(src_np.dtype)
+        jobs[i].M = M
+        jobs[i].dst.dst = dst_t.data_ptr()
+        jobs[i].dst.order = order.data_ptr() if order is not None else None
+        jobs[i].dst.dst_type = G.type_id(str(dst_t.dtype)[6:])
+        jobs[i].dst.dst_stride = dst_t.shape[1] if dst_t.dim() == 2 else 1
+        jobs[i].dst.dst_col0 = col0
+        jobs[i].dst.bitcast = 1 if bitcast else 0
+        if fill is not None:
+            np_dt = np.dtype(str(dst_t.dtype)[6:])
+            jobs[i].dst.fill_rest = 1
+            jobs[i].dst.fill_bits = int(np.array([fill], dtype=np_dt).view("u%d" % np_dt.itemsize)[0])
+    torch.cuda.synchronize()
+    rc = _lib.lib.pgsd_unpack_fields(len(specs), jobs, N, None)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N", [1, 63, 1000, 1025, 70001])
+def test_unpack_fill_makes_whole_rows_of_partial_chunks(N):
+    """pgsd_field_dst.fill_rest: velocity without a mass chunk -> (vx, vy, vz, 1.0) rows stored whole (float4 and
+    double4 destinations), xy + w chunks with z filled, a lone w chunk with xyz filled; poisoned destinations show
+    that every column is written."""
+    rng = np.random.default_rng(N + 11)
+    vel = G.rand_array(rng, (N, 3), np.float32)
+    xy = G.rand_array(rng, (N, 2), np.float32)
+    w = G.rand_array(rng, (N, 1), np.float32)
+    keep = []
+    v4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    d4 = torch.full((N, 4), 7.5, dtype=torch.float64, device="cuda")
+    q4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    w4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    unpack_filled([(vel, v4, 3, 0, None, False, 1.0), (vel, d4, 3, 0, None, False, -2.5),
+                   (xy, q4, 2, 0, None, False, None), (w, q4, 1, 3, None, False, 0.25),
+                   (w, w4, 1, 3, None, False, 0.0)], N, keep)
+    got = v4.cpu().numpy()
+    assert got[:, :3].tobytes() == vel.tobytes() and (got[:, 3] == 1.0).all()
+    got = d4.cpu().numpy()
+    assert (got[:, :3] == vel.astype(np.float64)).all() and (got[:, 3] == -2.5).all()
+    got = q4.cpu().numpy()
+    assert got[:, :2].tobytes() == xy.tobytes() and got[:, 3].tobytes() == w.tobytes() and (got[:, 2] == 0.25).all()
+    got = w4.cpu().numpy()
+    assert (got[:, :3] == 0.0).all() and got[:, 3].tobytes() == w.tobytes()
+
+
+def test_unpack_fill_on_the_generic_paths():
+    """fill_rest where rows are not assembled by the row kernel: a scatter index, 2-byte elements, five columns"""
+    N = 4099
+    rng = np.random.default_rng(12)
+    vel = G.rand_array(rng, (N, 3), np.float32)
+    order_np = rng.permutation(N).astype(np.int32)
+    order = dev(order_np)
+    s16 = rng.integers(-30000, 30000, size=(N, 2)).astype(np.int16)
+    keep = []
+    v4 = torch.full((N, 4), 7.5, dtype=torch.float32, device="cuda")
+    h5 = torch.full((N, 5), 77, dtype=torch.int16, device="cuda")
+    unpack_filled([(vel, v4, 3, 0, order, False, 1.0), (s16, h5, 2, 1, None, False, -3)], N, keep)
+    got = v4.cpu().numpy()
+    assert got[order_np, :3].tobytes() == vel.tobytes() and (got[:, 3] == 1.0).all()
+    got = h5.cpu().numpy()
+    assert (got[:, 1:3] == s16).all() and (got[:, 0] == -3).all() and (got[:, 3:] == -3).all()
+
+
+def test_read_frame_device_scalar4_without_mass_and_typeid_chunks(tmp_gsd):
+    """A file that holds position and velocity only: `read_frame_device(scalar4=True)` restores
+    pos4 = (x, y, z, type id 0) and vel4 = (vx, vy, vz, mass 1.0) through the chunks' fill, arrays allocated
+    uninitialised."""
+    import pgsd.hoomd as hoomd
+    N = 10_007
+    rng = np.random.default_rng(5)
+    pos, vel = G.rand_array(rng, (N, 3), np.float32), G.rand_array(rng, (N, 3), np.float32)
+    with hoomd.open(tmp_gsd, 'w') as t:
+        fr = hoomd.Frame()
+        fr.particles.N = N
+        fr.particles.position, fr.particles.velocity = pos, vel
+        t.append(fr)
+    with hoomd.open(tmp_gsd, 'r') as t:
+        assert not t.file.chunk_exists(0, 'particles/mass') and not t.file.chunk_exists(0, 'particles/typeid')
+        s = t.read_frame_device(0, scalar4=True)
+        p4, v4 = s.particles.pos4.cpu().numpy(), s.particles.vel4.cpu().numpy()
+        assert p4[:, :3].tobytes() == pos.tobytes() and (p4[:, 3].view(np.uint32) == 0).all()
+        assert v4[:, :3].tobytes() == vel.tobytes() and (v4[:, 3] == 1.0).all()
+        # a partition of it
+        s = t.read_frame_device(0, part=(1000, 2345), scalar4=True)
+        v4 = s.particles.vel4.cpu().numpy()
+        assert v4.shape == (2345, 4) and v4[:, :3].tobytes() == vel[1000:3345].tobytes() and (v4[:, 3] == 1.0).all()

@@ -228,5 +228,19 @@ int main(int argc, char** argv)
         return t;
     };
     run("twice U=4 cached (2 launches, begin of 1st to end of 2nd)", twice, true);
+    // round 3: two launches, pos rows only then vel rows only, EIGHT rows in flight per lane --
+    // the eight index loads, then the eight row loads issued back to back, the stores behind staggered
+    // s_waitcnt vmcnt(7..0) as the compiler schedules this loop shape (checked in the ISA)
+    const unsigned b8 = (unsigned)((N + 2047) / 2048);
+    auto twice8 = [&](Set& s) -> float
+    {
+        hipExtLaunchKernelGGL((major_kernel<8, false>), dim3(b8), dim3(256), 0, 0, e0, e1, 0, s.pos, s.vel, s.order, s.opos, s.ovel, s.oid, N, 0);
+        hipExtLaunchKernelGGL((major_kernel<8, false>), dim3(b8), dim3(256), 0, 0, nullptr, e2, 0, s.pos, s.vel, s.order, s.opos, s.ovel, s.oid, N, 1);
+        CK(hipEventSynchronize(e2));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e2));
+        return t;
+    };
+    run("twice U=8 cached (2 launches, 8 rows in flight per lane)", twice8, true);
     return 0;
     }

@@ -17,6 +17,7 @@ import gpu_common as G
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 iters = 40
 with_mass = len(sys.argv) > 2 and sys.argv[2] == "mass"   # velocity.w too: both arrays get whole rows
+with_fill = len(sys.argv) > 2 and sys.argv[2] == "fill"   # no mass chunk; velocity.w = 1.0 through fill_rest: whole rows
 sets = []
 for s in range(3):
     pos = torch.randn((N, 3), device="cuda")
@@ -37,6 +38,9 @@ for s in range(3):
         jobs[i].dst.dst_stride = 4
         jobs[i].dst.dst_col0 = c0
         jobs[i].dst.bitcast = bc
+        if with_fill and dst is vel4:
+            jobs[i].dst.fill_rest = 1
+            jobs[i].dst.fill_bits = 0x3F800000          # 1.0f
     sets.append((jobs, (pos, vel, tid, pos4, vel4, mass)))
 torch.cuda.synchronize()
 stream = torch.cuda.current_stream().cuda_stream
@@ -53,5 +57,7 @@ med = float(np.median(ts))
 pos, vel, tid, pos4, vel4, mass = sets[0][1]
 per = 64 if with_mass else 56
 ok = bool(torch.equal(pos4[:, :3], pos) and torch.equal(vel4[:, :3], vel) and torch.equal(pos4[:, 3].view(torch.int32), tid[:, 0]))
-print(json.dumps({"N": N, "mass": with_mass, "median_us": round(med * 1e6, 1), "min_us": round(float(ts.min()) * 1e6, 1),
+if with_fill:
+    ok = ok and bool((vel4[:, 3] == 1.0).all())
+print(json.dumps({"N": N, "mass": with_mass, "fill": with_fill, "median_us": round(med * 1e6, 1), "min_us": round(float(ts.min()) * 1e6, 1),
                   "algo_bytes_per_particle": per, "algo_GBps": round(per * N / med / 1e9, 1), "frac": round(per * N / med / 8e12, 3), "correct": ok}))
