@@ -222,6 +222,13 @@ extern "C"
        frame's exchange.  Collective like pgsd_end_frame when it turns batching off. */
     int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched);
     int pgsd_get_frame_exchange(struct pgsd_handle* handle);
+    /* Batched mode only: with `on`, the host rows of pgsd_write_chunk(..., all == true, data) are BORROWED UNTIL
+       THE FRAME'S EXCHANGE instead of for the call -- the caller promises to leave them alone until the next
+       pgsd_end_frame / pgsd_flush / pgsd_frame_exchange / pgsd_close (the contract device sources have anyway).
+       Such a chunk then waits in the queue like every other instead of resolving it at once, and a frame costs
+       ONE exchange whatever mix of host and device chunks it holds.  (The reference's contract -- rows borrowed
+       for the call -- is the default; pgsd.fl turns this on where it holds the arrays itself.) */
+    int pgsd_set_deferred_rows(struct pgsd_handle* handle, int on);
     /* Perform the exchange now (collective; nothing is flushed): afterwards the queue is empty and the
        handle's mirror is current.  No-op when nothing is queued. */
     int pgsd_frame_exchange(struct pgsd_handle* handle);

@@ -195,6 +195,7 @@ struct Impl
     // frame-batched exchange: chunk writes that do not need their file offset at once are queued and
     // ONE allgather per frame (at pgsd_end_frame) carries their sizes and the ranks' status
     bool batch = false;
+    bool defer_rows = false; // batched: host rows of all == true chunks stay valid until the exchange (pgsd_set_deferred_rows)
     bool unsynced = false; // a batched frame was sealed that no barrier between the ranks has covered yet
     std::vector<Queued> queue;
 
@@ -1551,8 +1552,11 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
             {
             q.borrowed = local == PGSD_SUCCESS ? data : nullptr;
             s->queue.push_back(std::move(q));
-            const int qrc = resolve_queue(s);
-            rc = local != PGSD_SUCCESS ? local : qrc;
+            if (!s->defer_rows) // rows borrowed for the call only: place them (and everything queued before) now
+                {
+                const int qrc = resolve_queue(s);
+                rc = local != PGSD_SUCCESS ? local : qrc;
+                }
             }
         else
             {
@@ -1857,6 +1861,24 @@ extern "C" int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched)
     if (!batched && s->batch && s->flags != PGSD_OPEN_READONLY)
         rc = do_flush(s); // leave nothing queued and nothing unsynchronised behind
     s->batch = batched != 0;
+    publish(handle, s);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_set_deferred_rows(struct pgsd_handle* handle, int on)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = PGSD_SUCCESS;
+    if (!on && s->defer_rows && !s->queue.empty()) // rows queued under the promise are placed while it still holds
+        rc = resolve_queue(s);
+    s->defer_rows = on != 0;
     publish(handle, s);
     return rc;
     }

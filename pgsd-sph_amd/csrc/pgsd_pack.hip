@@ -1371,9 +1371,21 @@ static RowsCfg rows_config(uint64_t N, uint32_t n_groups)
     RowsCfg c = (N < (2u << 20) && n_groups <= 2) ? RowsCfg {256, 4} : RowsCfg {256, 2};
     if (const char* e = getenv("PGSD_PACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
         {
+        // only the instantiated pairs (launch_rows below): the grid is sized from T x U, so a pair the
+        // dispatcher does not know would pack too few rows per block and leave a part of every chunk unwritten
         int t = 0, u = 0;
-        if (sscanf(e, "%dx%d", &t, &u) == 2)
+        const bool known = sscanf(e, "%dx%d", &t, &u) == 2
+                           && ((t == 64 && u == 2) || (t == 128 && (u == 1 || u == 2))
+                               || (t == 256 && (u == 1 || u == 2 || u == 4 || u == 8)) || (t == 512 && (u == 2 || u == 4)));
+        if (known)
             c = RowsCfg {t, u};
+        else
+            {
+            static bool warned = false;
+            if (!warned)
+                fprintf(stderr, "pgsd_amd: PGSD_PACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2 256x4 256x8 512x2 512x4: ignored\n", e);
+            warned = true;
+            }
         }
     return c;
     }
@@ -1750,7 +1762,19 @@ static void launch_unrows(const UnrowsPlan& p, uint64_t N, hipStream_t stream)
     // 102.4-103.0 us, 128 x 1 104.6-105.0 us, 256 x 2 105.9-106.0 us (10 M particles, stream events)
     int T = 64, U = 2;
     if (const char* e = getenv("PGSD_UNPACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
-        (void)sscanf(e, "%dx%d", &T, &U);
+        {
+        int t = 0, u = 0;
+        if (sscanf(e, "%dx%d", &t, &u) == 2
+            && ((t == 64 && u == 2) || (t == 128 && (u == 1 || u == 2)) || (t == 256 && (u == 1 || u == 2))))
+            T = t, U = u;
+        else
+            {
+            static bool warned = false;
+            if (!warned)
+                fprintf(stderr, "pgsd_amd: PGSD_UNPACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2: ignored\n", e);
+            warned = true;
+            }
+        }
     UnrowsArgs a = p.args;
     a.n_blocks = (N + (uint64_t)T * U - 1) / ((uint64_t)T * U);
     const dim3 grid((unsigned)a.n_blocks, a.n_groups);

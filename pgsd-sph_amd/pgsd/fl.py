@@ -257,6 +257,7 @@ class PGSDFile(object):
         self.__keepalive = []
         self.__explicit_stream = False
         self.__source_stream = -1       # what the pipeline was last told (-1: nothing yet)
+        self.__deferred_rows = False
         self.__async_keep = []
 
         if overwrite:
@@ -370,6 +371,21 @@ class PGSDFile(object):
         self._check_open()
         _raise_on_error(lib.pgsd_set_frame_exchange(self._h(), 1 if on else 0), self.__name)
 
+    @property
+    def deferred_rows(self):
+        """bool: with :attr:`frame_exchange` on, host arrays written with ``write_all=True`` wait for the frame's
+        exchange like every other chunk instead of forcing one at once (``pgsd_set_deferred_rows``): the file object
+        keeps the arrays alive until then, and the CALLER must not change them before :meth:`end_frame` /
+        :meth:`flush` / :meth:`exchange_now` (the rule device tensors follow anyway).  A frame then costs one
+        exchange whatever it holds."""
+        return self.__deferred_rows
+
+    @deferred_rows.setter
+    def deferred_rows(self, on):
+        self._check_open()
+        _raise_on_error(lib.pgsd_set_deferred_rows(self._h(), 1 if on else 0), self.__name)
+        self.__deferred_rows = bool(on)
+
     def exchange_now(self):
         """Perform the pending frame exchange now (collective; nothing is flushed)."""
         self._check_open()
@@ -423,6 +439,8 @@ class PGSDFile(object):
         N_global, stride = self._partition_args(offset, rank, N, M)
         pgsd_type = _pgsd_type(data_array.dtype, name)
         ptr = data_array.ctypes.data if data_array.size else None
+        if self.__deferred_rows and write_all:
+            self.__keepalive.append(data_array)     # the rows are read at the frame's exchange, not now
         logger.debug('write chunk: ' + self.__name + ' - ' + name)
         ctypes.set_errno(0)
         retval = lib.pgsd_write_chunk(self._h(), name.encode('utf-8'), pgsd_type, N, M, N_global, M,

@@ -383,11 +383,15 @@ class HOOMDTrajectory(object):
                     if self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
                         self._frame0_chunks.add(path + '/' + name)
 
-        # From here on the frame costs two collectives however many chunks it has: the allgather below
-        # (row counts + write/skip votes) and the one frame exchange of end_frame, which places every
-        # queued chunk (pgsd_set_frame_exchange; the file is byte-identical to the unbatched one).
+        # From here on the frame costs two collectives however many chunks of whatever kind it has: the
+        # allgather below (row counts + write/skip votes) and the one frame exchange of end_frame, which places
+        # every queued chunk (pgsd_set_frame_exchange; the file is byte-identical to the unbatched one).  Host
+        # arrays wait for that exchange too (deferred_rows: this method holds them until end_frame returns)
+        # instead of forcing an exchange each, and so do state/* and log/* chunks.
         if getattr(self.file, 'frame_exchange', None) is False:
             self.file.frame_exchange = True
+        if getattr(self.file, 'deferred_rows', None) is False:
+            self.file.deferred_rows = True
 
         # 1. decide locally which chunks to write, then ONE allgather carries every rank's particle count
         #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes

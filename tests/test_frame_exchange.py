@@ -324,3 +324,35 @@ def test_bad_arguments_on_one_rank_fail_the_call_everywhere_without_a_hang(batch
     # the replicated chunk: the rank with the NULL pointer knows at once; everyone by the end of the frame
     r0, r1 = results[0][1], results[1][1]
     assert r1[1] == -2 and (r0[1] == -2 or r0[2] == -2)
+
+
+def test_hoomd_append_costs_two_collectives_per_frame_for_host_arrays_too(mirror, tmp_path):
+    """`HOOMDTrajectory.append` at P > 1: the row-count / vote allgather and ONE frame exchange, however many host
+    arrays, state and log chunks the frame holds (round 2: every host per-particle chunk and every log chunk forced
+    an exchange of its own -- ADVICE r2).  The arrays wait for the exchange (`deferred_rows`)."""
+    import pgsd.hoomd as hoomd
+    t = hoomd.open(str(tmp_path / "h.gsd"), "w")
+    rng = np.random.default_rng(1)
+    per_frame = []
+    for i in range(4):
+        fr = hoomd.Frame()
+        fr.configuration.step = i
+        fr.particles.N = 50
+        fr.particles.position = rng.random((50, 3), dtype=np.float32)
+        fr.particles.velocity = rng.random((50, 3), dtype=np.float32)
+        fr.particles.typeid = rng.integers(0, 3, size=50).astype(np.uint32)
+        fr.particles.density = rng.random(50, dtype=np.float32)
+        fr.log["energy"] = np.array([1.5 * i])
+        fr.log["virial"] = np.arange(6, dtype=np.float64) + i
+        fr.state["hpmc/d"] = np.array([0.1 * i])
+        n0 = len(mirror.calls)
+        t.append(fr)
+        per_frame.append(len(mirror.calls) - n0)
+    assert t.file.deferred_rows and t.file.frame_exchange
+    # (the second append reads frame 0 back as its elision reference: a read is a synchronisation point and
+    # makes up the barrier the batched frame 0 skipped -- once per trajectory)
+    assert per_frame == [2, 3, 2, 2], per_frame
+    t.close()
+    with hoomd.open(str(tmp_path / "h.gsd"), "r") as r:
+        assert len(r) == 4 and r[3].particles.N == 100                 # the mirrored peer wrote the same rows
+        assert r[2].log["energy"][0] == 3.0

@@ -348,3 +348,30 @@ def test_config2_one_mebi_rows_position_velocity_id(layout):
         check(o_id, G.oracle_pack(ids.view(np.int32).reshape(N, 1), 1, out_dtype=np.uint32))
     assert (o_id.cpu().numpy()[:4 * N].view(np.uint32) == ids).all()
     assert int(o_id.cpu().numpy()[:4 * N].view(np.uint32).astype(np.int64).sum()) == N * (N - 1) // 2
+
+
+@pytest.mark.parametrize("cfg", ["64x4", "1024x1", "0x0", "junk", "256x8"])
+def test_unknown_rows_tuning_pair_is_ignored_not_obeyed(cfg, monkeypatch):
+    """PGSD_PACK_ROWS_CFG / PGSD_UNPACK_ROWS_CFG name launch shapes for tuning sweeps.  A pair that is not
+    instantiated used to size the grid from the requested T x U while the kernel ran the 128 x 1 fallback: part of
+    every chunk stayed unwritten ('0x0' divided by zero).  Unknown pairs are now ignored."""
+    monkeypatch.setenv("PGSD_PACK_ROWS_CFG", cfg)
+    monkeypatch.setenv("PGSD_UNPACK_ROWS_CFG", cfg)
+    N = 70_001
+    rng = np.random.default_rng(3)
+    pos = G.rand_array(rng, (N, 4), np.float32)
+    d = dev(pos)
+    out, w = empty_out(N, 3, np.float32), empty_out(N, 1, np.float32)
+    G.hip_pack([(out, np.float32, 3, d, 0, None, False), (w, np.float32, 1, d, 3, None, False)], N)
+    check(out, G.oracle_pack(pos, 3))
+    check(w, G.oracle_pack(pos, 1, col0=3))
+    from pgsd import _lib
+    back = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    jobs = (_lib.UnpackJob * 2)()
+    for i, (chunk, M, c0) in enumerate(((out, 3, 0), (w, 1, 3))):
+        jobs[i].src, jobs[i].src_type, jobs[i].M = chunk.data_ptr(), 9, M
+        jobs[i].dst.dst, jobs[i].dst.dst_type, jobs[i].dst.dst_stride, jobs[i].dst.dst_col0 = back.data_ptr(), 9, 4, c0
+    torch.cuda.synchronize()
+    assert _lib.lib.pgsd_unpack_fields(2, jobs, N, None) == 0
+    torch.cuda.synchronize()
+    assert back.cpu().numpy().tobytes() == pos.tobytes()
