@@ -14,9 +14,11 @@ def _build_if_missing():
     oracle before collection imports them. The product itself still refuses to run without its
     library; this only saves the `python -c "import __graft_entry__ as g; g.build()"` step."""
     import subprocess
+    import glob
     lib = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
     drv = os.path.join(ROOT, "pgsd-sph_amd", "csrc", "build", "scenario_driver")
-    if not (os.path.exists(lib) and os.path.exists(drv)):
+    ext = glob.glob(os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "_fl.*.so"))      # the Cython file layer (pgsd.fl)
+    if not (os.path.exists(lib) and os.path.exists(drv) and ext):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "pgsd-sph_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "oracle", "libpgsd_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)

@@ -254,11 +254,11 @@ def test_async_frames_do_not_pin_their_source_tensors(tmp_gsd):
         del t
     import gc
     gc.collect()
-    assert len(f._PGSDFile__async_keep) <= 2
+    assert f._async_frames_kept() <= 2
     assert sum(r() is not None for r in refs) <= 2
     f.flush()
     gc.collect()
-    assert not f._PGSDFile__async_keep and all(r() is None for r in refs)
+    assert f._async_frames_kept() == 0 and all(r() is None for r in refs)
     f.close()
     g = fl.open(tmp_gsd, "r")
     assert g.nframes == 12
