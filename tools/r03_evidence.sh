@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, sixth GPU pass: the round's evidence -- kernel stats + PMC (10 M, 2^20), config 2, bench lines, rehearsals,
+# round 3: the evidence run behind profiles/r03_* (gpurun -- bash tools/r03_evidence.sh): kernel stats + PMC (10 M, 2^20), config 2, bench lines, rehearsals,
 # the phase timeline of a 10 M frame, the unpack fill under the profiler
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_pass6
+O=$GRAFT_REPO_ROOT/gpurun_out/r03_evidence
 mkdir -p $O
 export TMPDIR=/tmp
 bash tools/profile_pack.sh r03 > $O/profile_pack.log 2>&1; echo "profile_pack rc=$?" | tee -a $O/summary.txt
