@@ -184,8 +184,8 @@ struct ReadEngine
     };
 
 // What a pipeline needs from the HIP runtime is expensive to make and to give back: two streams (ms each),
-// pinned slabs (2-3 ms per 16 MiB hipHostMalloc, more to free), the pinned arena of the direct path, an HBM
-// arena, events.  A trajectory writer that opens one file per snapshot (or a benchmark that re-creates its
+// pinned slabs (2-3 ms per 16 MiB hipHostMalloc, more to free), the pinned arena of the direct path, HBM
+// arenas, events.  A trajectory writer that opens one file per snapshot (or a benchmark that re-creates its
 // file) paid 20-30 ms per open/close for them.  A closed pipeline of the default geometry therefore parks its
 // resources here, at most two sets per process, and the next pipeline on the same device adopts them.
 // Never freed at exit: no HIP calls from static destruction.
@@ -198,8 +198,7 @@ struct ParkedResources
     char* dhost = nullptr;
     char* ddev = nullptr;
     size_t dcap = 0;
-    char* arena = nullptr;
-    size_t arena_cap = 0;
+    std::vector<char*> arenas; // HBM staging arenas of the default size (256 MiB each)
     std::vector<hipEvent_t> ev_plain, ev_timing;
     };
 
@@ -262,8 +261,8 @@ class DevicePipeline
             m_pack_stream = adopted.pack_stream;
             m_copy_stream = adopted.copy_stream;
             m_dhost = adopted.dhost, m_ddev = adopted.ddev, m_dcap = adopted.dcap;
-            if (adopted.arena)
-                m_arenas.push_back({adopted.arena, adopted.arena_cap, 0});
+            for (char* a : adopted.arenas)
+                m_arenas.push_back({a, (size_t)256 << 20, 0});
             m_pool_plain = std::move(adopted.ev_plain);
             m_pool_timing = std::move(adopted.ev_timing);
             }
@@ -381,7 +380,7 @@ class DevicePipeline
 
     // Hand streams, pinned memory, one HBM arena and the idle events to the next pipeline on this device
     // (see ParkedResources).  Only a healthy pipeline of the default slab size, only while fewer than two sets
-    // are parked, and only what a default pipeline would hold: at most four slabs, one arena of the default size.
+    // are parked, and only what a default pipeline would hold: at most four slabs, four arenas of the default size.
     bool park()
         {
         const uint64_t default_slab = (uint64_t)16 << 20;
@@ -419,8 +418,10 @@ class DevicePipeline
         r.dhost = m_dhost, r.ddev = m_ddev, r.dcap = m_dcap;
         for (auto& a : m_arenas)
             {
-            if (!r.arena && a.cap == ((size_t)256 << 20))
-                r.arena = a.base, r.arena_cap = a.cap;
+            // up to 1 GiB of staging stays with the set (a run of asynchronously sealed frames grows into it;
+            // giving 256 MiB blocks back and asking for them again cost 3-5 ms apiece)
+            if (r.arenas.size() < 4 && a.cap == ((size_t)256 << 20))
+                r.arenas.push_back(a.base);
             else
                 (void)hipFree(a.base);
             }
@@ -627,6 +628,31 @@ class DevicePipeline
                            });
         }
 
+    // host bytes (an asynchronously sealed frame's metadata) written by the writer thread, behind what is queued
+    void write_host(const void* data, size_t bytes, long long file_offset)
+        {
+        if (bytes == 0)
+            return;
+        auto copy = std::make_shared<std::vector<char>>((const char*)data, (const char*)data + bytes);
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            m_outstanding += 1;
+            }
+        writer_pool_submit(m_pool,
+                           [this, copy, file_offset]
+                           {
+                               int w = pwrite_locked(m_fd, copy->data(), copy->size(), file_offset, m_shared);
+                               if (w != 0)
+                                   fail(std::string("pwrite: ") + strerror(-w), true, -w);
+                               piece_done(0, 0);
+                           });
+        }
+
+    bool single_writer() const
+        {
+        return m_cfg.n_writers == 1;
+        }
+
     bool staged_open()
         {
         std::lock_guard<std::mutex> g(m_mutex);
@@ -641,6 +667,43 @@ class DevicePipeline
         if (failed())
             return PGSD_ERROR_DEVICE;
         HIP_TRY(hipSetDevice(m_cfg.device));
+        const size_t padded = (bytes + 255) & ~(size_t)255;
+        if (bytes > 0 && bytes <= m_direct_max && direct_reserve(padded))
+            {
+            // Small read, the short road (twin of the direct write path): THIS thread preads the rows straight
+            // into the pinned, device-mapped arena and the unpack kernel fetches them from there over PCIe --
+            // no reader-thread hand-over, no host->device copy, no staging in HBM.  For a frame of a few
+            // thousand particles those fixed costs were ten times the read itself.
+            char* host = m_dhost + m_dused;
+            job.src = m_ddev + m_dused;
+            m_dused += padded;
+                {
+                TraceRange tr("pgsd:pread_direct file_off=%llu bytes=%llu", (unsigned long long)file_offset, bytes);
+                size_t got = 0;
+                while (got < bytes)
+                    {
+                    ssize_t r = pread(m_fd, host + got, bytes - got, (off_t)(file_offset + (long long)got));
+                    if (r < 0 && errno == EINTR)
+                        continue;
+                    if (r <= 0)
+                        break;
+                    got += (size_t)r;
+                    }
+                if (got != bytes)
+                    {
+                    fail("pread returned fewer bytes than the chunk holds", true);
+                    return PGSD_SUCCESS; // reported by pgsd_device_wait_read, like the threaded path
+                    }
+                }
+            auto direct_req = std::make_shared<ReadReq>();
+            direct_req->job = job;
+            direct_req->N = N;
+            direct_req->pieces_left = 0;
+            direct_req->all_copied = nullptr; // nothing to wait for: the bytes are there
+            std::lock_guard<std::mutex> g(m_copy_mutex);
+            m_unpack_pending.push_back(direct_req);
+            return PGSD_SUCCESS;
+            }
         void* stage = nullptr;
         int rc = arena_alloc(bytes, &stage);
         if (rc != PGSD_SUCCESS)
@@ -683,7 +746,7 @@ class DevicePipeline
         lk.unlock();
         (void)hipSetDevice(m_cfg.device);
         launch_pending_unpacks();
-        hipError_t e = hipStreamSynchronize(m_copy_stream);
+        hipError_t e = m_copy_used.exchange(false) ? hipStreamSynchronize(m_copy_stream) : hipSuccess;
         if (e == hipSuccess)
             e = hipStreamSynchronize(m_pack_stream);
         if (e != hipSuccess)
@@ -1193,7 +1256,7 @@ class DevicePipeline
                     continue;
                     }
                 jobs.push_back(r->job);
-                if (e == hipSuccess)
+                if (e == hipSuccess && r->all_copied) // (direct reads have no copy to wait for)
                     e = hipStreamWaitEvent(m_pack_stream, r->all_copied, 0);
                 }
             // The destinations belong to the caller: whatever its stream still has in flight on them
@@ -1416,6 +1479,16 @@ int device_pipeline_commit(DevicePipeline* p, int ticket, size_t index, long lon
 void device_pipeline_kick(DevicePipeline* p)
     {
     p->kick_direct();
+    }
+
+void device_pipeline_write_host(DevicePipeline* p, const void* data, size_t bytes, long long file_offset)
+    {
+    p->write_host(data, bytes, file_offset);
+    }
+
+bool device_pipeline_single_writer(DevicePipeline* p)
+    {
+    return p->single_writer();
     }
 
 int device_pipeline_wait_packed(DevicePipeline* p, std::string* err)

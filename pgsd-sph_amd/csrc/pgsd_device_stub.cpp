@@ -18,6 +18,8 @@ int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t,
 int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, int*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_commit(DevicePipeline*, int, size_t, long long, void*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 void device_pipeline_kick(DevicePipeline*) { }
+void device_pipeline_write_host(DevicePipeline*, const void*, size_t, long long) { }
+bool device_pipeline_single_writer(DevicePipeline*) { return false; }
 int device_pipeline_wait_packed(DevicePipeline*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 void device_pipeline_set_source_stream(DevicePipeline*, void*) { }
 int device_pipeline_read(DevicePipeline*, long long, size_t, const pgsd_unpack_job&, uint64_t, std::string*) { return PGSD_ERROR_NO_DEVICE; }

@@ -111,6 +111,10 @@ int device_pipeline_commit(DevicePipeline*, int ticket, size_t index, long long 
                            std::string* err);
 // asynchronous seal: chunks of the direct (small-frame) path are handed to the writer thread now
 void device_pipeline_kick(DevicePipeline*);
+// a few host bytes (metadata of an asynchronously sealed frame) through the writer thread, in FIFO order behind the
+// pieces already queued; copied.  single_writer: that order is only defined with one writer thread
+void device_pipeline_write_host(DevicePipeline*, const void* data, size_t bytes, long long file_offset);
+bool device_pipeline_single_writer(DevicePipeline*);
 int device_pipeline_wait_packed(DevicePipeline*, std::string* err);
 void device_pipeline_set_source_stream(DevicePipeline*, void* stream);
 // read side: rows at `file_offset` -> staging -> unpack into job.dst (job.src is filled in)

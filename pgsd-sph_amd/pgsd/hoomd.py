@@ -695,6 +695,7 @@ class HOOMDTrajectory(object):
 
         specs = list(_PARTICLE_SPEC.items()) + list(_PARTICLE_SPEC_EXTRA.items())
         n_frame0 = None          # frame 0's arrays stand in only while the particle count is frame 0's (hoomd.py:858-884)
+        default_rows = None      # this read's own copy of the default rows (one small device-to-device copy, below)
         for name, (dt, M) in specs:
             chunk = 'particles/' + name
             fr = frame_of(chunk)
@@ -708,10 +709,13 @@ class HOOMDTrajectory(object):
             elif name in snap.particles._default_value:
                 # like the host reader (hoomd.py:872-881) a default is ONE row broadcast over the particles: no
                 # N-row allocation, no copy; `.contiguous()` / `.clone()` gives an array of its own.  The reference
-                # marks its defaults read-only; torch has no such flag, so the row is built afresh for every
-                # read: a write through the view changes this frame's view only, never a later frame's default
-                default = numpy.broadcast_to(numpy.asarray(snap.particles._default_value[name], dtype=dt), (M,))
-                row = torch.as_tensor(numpy.array(default)).to('cuda')      # (a writable copy: torch refuses read-only views)
+                # marks its defaults read-only; torch has no such flag, so every read gets its OWN copy of the rows
+                # (one clone of a 40-word template per frame, not one host->device copy per field): a write
+                # through a view changes this frame's view only, never a later frame's default
+                if default_rows is None:
+                    default_rows = self._default_rows_template().clone()
+                off, words, tdt = self._default_rows_layout[name]
+                row = default_rows[off:off + words].view(tdt)
                 setattr(snap.particles, name, row.expand(n, M) if M > 1 else row.expand(n))
         if scalar4 and n >= 0:
             # HOOMD's Scalar4 arrays, every row stored WHOLE by the unpack launch: the columns a missing chunk
@@ -741,6 +745,25 @@ class HOOMDTrajectory(object):
             if f.chunk_exists(idx, state):
                 snap.state[state[6:]] = f.read_chunk(idx, state)
         return snap
+
+    def _default_rows_template(self):
+        """All default rows of the SPH schema as ONE int32 device tensor (every element type of the schema is four
+        bytes wide), built once per trajectory and device; `_default_rows_layout[name]` = (first word, words, torch
+        dtype).  `read_frame_device` clones it per read and hands out views of the clone."""
+        import torch
+        dev = torch.cuda.current_device()
+        cached = getattr(self, '_default_rows_cache', None)
+        if cached is not None and cached[0] == dev:
+            return cached[1]
+        words, layout = [], {}
+        for name, (dt, M) in _PARTICLE_SPEC.items():
+            row = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(ParticleData._default_value[name], dtype=dt), (M,)))
+            layout[name] = (len(words), M, getattr(torch, numpy.dtype(dt).name))
+            words += row.view(numpy.int32).tolist()
+        template = torch.tensor(words, dtype=torch.int32, device='cuda')
+        self._default_rows_layout = layout
+        self._default_rows_cache = (dev, template)
+        return template
 
     def _read_scalar_any(self, idx, chunk, container, attr):
         f = self.file

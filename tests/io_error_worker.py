@@ -23,7 +23,7 @@ import pgsd.fl as fl
 
 if nranks > 1:
     pdist.init_shm(shm, rank, nranks)
-N = 300_000
+N = int(os.environ.get("PGSD_IOERR_N", "300000"))      # 3.6 MB per frame: the pipeline; 100 000 -> 1.2 MB: the direct path
 counts = np.array([N] * nranks, dtype=np.uint64)
 report = {"rank": rank, "events": []}
 f = fl.open(path, 'w', application='io-error test', schema='s', schema_version=[1, 0])

@@ -15,11 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "io_error_worker.py")
 
 
-def run_ranks(path, nranks, limited_rank, device, batched=False):
+def run_ranks(path, nranks, limited_rank, device, batched=False, rows=None):
     shm = "pgsdioerr_%s" % uuid.uuid4().hex[:10]
+    env = dict(os.environ) if rows is None else dict(os.environ, PGSD_IOERR_N=str(rows))
     procs = [subprocess.Popen([sys.executable, WORKER, path, str(r), str(nranks), shm,
                                "1" if r == limited_rank else "0", "1" if device else "0", "1" if batched else "0"],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(nranks)]
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(nranks)]
     reports = []
     try:
         for p in procs:
@@ -94,3 +95,15 @@ def test_write_failure_with_batched_frame_exchange_reaches_all_ranks(limited_ran
 @pytest.mark.gpu
 def test_device_write_failure_with_batched_frame_exchange_two_ranks(tmp_gsd):
     check_batched(run_ranks(tmp_gsd, 2, 1, device=True, batched=True), 1, device=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks,batched", [(1, False), (2, False), (2, True)])
+def test_direct_path_write_failure(nranks, batched, tmp_gsd):
+    """Frames small enough for the direct path (1.2 MB: packed straight into pinned host memory, pwrite()n by the
+    thread that seals the frame): the failing pwrite is reported by end_frame on every rank, like the pipeline's."""
+    reports = run_ranks(tmp_gsd, nranks, nranks - 1, device=True, batched=batched, rows=100_000)
+    if batched:
+        check_batched(reports, nranks - 1, device=True)
+    else:
+        check(reports, nranks - 1, device=True)
