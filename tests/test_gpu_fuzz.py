@@ -107,12 +107,15 @@ def test_random_fused_unpack(seed):
     from pgsd import _lib
     specs = []       # (chunk np, dst index, M, col0, bitcast)
     dsts = []        # (tensor bytes view, dtype, stride, order np or None, device order)
+    fills = {}       # dst index -> fill element (pgsd_field_dst.fill_rest), for about a third of the arrays
     for _ in range(int(rng.integers(1, 5))):
         ddt = str(rng.choice(["float32", "float32", "float64", "int32", "uint32", "int64", "uint16", "uint8"]))
         stride = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 16]))
         order = rng.permutation(N).astype(np.uint32) if rng.random() < 0.3 else None
         t = torch.full((N, stride * np.dtype(ddt).itemsize), 0x5A, dtype=torch.uint8, device="cuda")
         dsts.append((t, ddt, stride, order, torch.from_numpy(order.view(np.int32)).cuda() if order is not None else None))
+        if rng.random() < 0.35:
+            fills[len(dsts) - 1] = G.rand_array(rng, (1,), ddt)[0]
         # split the columns into chunks; sometimes leave a hole
         col = 0
         while col < stride:
@@ -148,6 +151,10 @@ def test_random_fused_unpack(seed):
         jobs[k].dst.dst_stride = stride
         jobs[k].dst.dst_col0 = col0
         jobs[k].dst.bitcast = 1 if bitcast else 0
+        if di in fills:
+            # columns of this array's rows that NO chunk of the launch writes take the fill element
+            jobs[k].dst.fill_rest = 1
+            jobs[k].dst.fill_bits = int(np.array([fills[di]], dtype=ddt).view("u%d" % np.dtype(ddt).itemsize)[0])
     torch.cuda.synchronize()
     rc = _lib.lib.pgsd_unpack_fields(len(specs), jobs, N, None)
     assert rc == 0, _lib.last_error()
@@ -155,6 +162,8 @@ def test_random_fused_unpack(seed):
     for di, (t, ddt, stride, order, _) in enumerate(dsts):
         got = t.cpu().numpy().view(ddt).reshape(N, stride)
         exp = np.frombuffer(bytes([0x5A]) * (N * stride * np.dtype(ddt).itemsize), dtype=ddt).reshape(N, stride).copy()
+        if di in fills and any(dj == di for _, dj, _, _, _ in specs):
+            exp[:, :] = fills[di]       # every row is touched (the scatter index is a permutation): holes = the fill
         for chunk, dj, M, col0, bitcast in specs:
             if dj != di:
                 continue
