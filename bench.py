@@ -238,21 +238,36 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    import signal
+
+    def stop_children(signum, frame):           # the launcher is told to stop: so are its ranks (exactly these PIDs)
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, stop_children)
     status = 0
     pending = list(procs)
-    while pending:
-        for p in list(pending):
-            rc = p.poll()
-            if rc is None:
-                continue
-            pending.remove(p)
-            if rc != 0 and status == 0:
-                status = rc if rc > 0 else 1
-                # a rank that died leaves the others inside a collective: end them (exactly these children)
-                for q in pending:
-                    q.terminate()
-        if pending:
-            time.sleep(0.05)
+    try:
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    # a rank that died leaves the others inside a collective: end them (exactly these children)
+                    for q in pending:
+                        q.terminate()
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
     return status
 
 

@@ -1253,7 +1253,10 @@ static int resolve_queue(Impl* s)
         const int drc = deliver_chunk(s, q, pl, rc != PGSD_SUCCESS);
         if (rc == PGSD_SUCCESS)
             rc = drc;
-        if (rc != PGSD_SUCCESS && first_rc == PGSD_SUCCESS)
+        // A chunk that failed THIS rank's own check was refused when it was written (the call returned the code,
+        // as the reference's does, pgsd.c:2090-2105); the resolving call reports what this rank has not been told
+        // yet: another rank's refusal of a chunk, or a delivery that failed now.
+        if (rc != PGSD_SUCCESS && first_rc == PGSD_SUCCESS && q.local_rc == PGSD_SUCCESS)
             first_rc = rc;
         }
     return first_rc;

@@ -43,7 +43,9 @@
  *   chunkgs <name> <type> <M> <all> <dist> <global_size>
  *         (as chunk, but the caller's global_size argument is the given value, right or wrong:
  *          the reference ignores it, pgsd.c:2147-2151, 2240-2246)
- *   batch <0|1>                    (product only: pgsd_set_frame_exchange; ignored by the reference build.
+ *   batch <0|1|2>                  (product only: pgsd_set_frame_exchange; 2 = batched + pgsd_set_deferred_rows: the
+ *                                   driver then keeps every chunk's rows until the next end_frame / flush / close / dump;
+ *                                   ignored by the reference build.
  *                                   `dump` then performs the pending exchange first, so that the trace
  *                                   shows the same file_size the unbatched run shows)
  *   end_frame | flush | close | dump
@@ -233,6 +235,27 @@ static enum pgsd_open_flag parse_flag(const char* s)
     exit(2);
     }
 
+/* rows of chunk writes that must outlive the call (batch 2: pgsd_set_deferred_rows): freed at the next
+   end_frame / flush / close / dump, all of which resolve the queue */
+static void* g_kept[65536];
+static int g_nkept = 0;
+static int g_defer = 0;
+
+static void release_rows(void* data)
+    {
+    if (g_defer && g_nkept < (int)(sizeof(g_kept) / sizeof(g_kept[0])))
+        g_kept[g_nkept++] = data;
+    else
+        free(data);
+    }
+
+static void free_kept_rows(void)
+    {
+    for (int i = 0; i < g_nkept; i++)
+        free(g_kept[i]);
+    g_nkept = 0;
+    }
+
 int main(int argc, char** argv)
     {
     if (argc < 3)
@@ -342,7 +365,7 @@ int main(int argc, char** argv)
                 rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, N, M, 0, N * M,
                                       false, 0, data);
                 }
-            free(data);
+            release_rows(data);
             }
         else if (strcmp(cmd, "chunkgs") == 0 && nt == 7)
             {
@@ -363,7 +386,7 @@ int main(int argc, char** argv)
             void* data = gen_data(type, seed, row0, N, M, sz);
             rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M, gs, all != 0, 0,
                                   data);
-            free(data);
+            release_rows(data);
             }
         else if ((strcmp(cmd, "rawchunk") == 0 || strcmp(cmd, "samechunk") == 0) && nt == 10)
             {
@@ -379,14 +402,23 @@ int main(int argc, char** argv)
             void* data = gen_data(type, cmd[0] == 's' ? seed : seed + (uint64_t)g_rank, 0, N, M, sz);
             rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, Mg, off, gs,
                                   all != 0, 0, data);
-            free(data);
+            release_rows(data);
             }
         else if (strcmp(cmd, "end_frame") == 0)
+            {
             rc = pgsd_end_frame(&handle);
+            free_kept_rows();
+            }
         else if (strcmp(cmd, "flush") == 0)
+            {
             rc = pgsd_flush(&handle);
+            free_kept_rows();
+            }
         else if (strcmp(cmd, "close") == 0)
+            {
             rc = pgsd_close(&handle);
+            free_kept_rows();
+            }
         else if (strcmp(cmd, "maxbuf") == 0 && nt == 2)
             rc = pgsd_set_maximum_write_buffer_size(&handle, strtoull(tok[1], NULL, 10));
         else if (strcmp(cmd, "idxbuf") == 0 && nt == 2)
@@ -394,14 +426,24 @@ int main(int argc, char** argv)
         else if (strcmp(cmd, "batch") == 0 && nt == 2)
             {
 #ifndef PGSD_DRIVER_REF
-            rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]));
+            rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]) != 0);
+            if (rc == 0 && atoi(tok[1]) == 2)
+                {
+                rc = pgsd_set_deferred_rows(&handle, 1);
+                g_defer = 1;
+                }
+            else
+                g_defer = 0;
 #endif
             }
         else if (strcmp(cmd, "dump") == 0)
             {
 #ifndef PGSD_DRIVER_REF
             if (pgsd_get_frame_exchange(&handle))
+                {
                 rc = pgsd_frame_exchange(&handle);
+                free_kept_rows();
+                }
 #endif
             uint64_t nf = pgsd_get_nframes(&handle);
             uint64_t nn = pgsd_get_nnames(&handle);

@@ -50,8 +50,9 @@ def run_driver(script, out_path, P, timeout=120, allow_fail=False):
     return [ln for ln in out.decode().splitlines() if ln.strip()]
 
 
-def batched_script(path, out_path):
-    """The same scenario with the frame exchange batched (pgsd_set_frame_exchange) on every handle."""
+def batched_script(path, out_path, mode=1):
+    """The same scenario with the frame exchange batched (pgsd_set_frame_exchange) on every handle; mode 2: and the
+    rows of per-particle host chunks deferred to the frame's exchange (pgsd_set_deferred_rows)."""
     lines = []
     with open(path) as f:
         for line in f:
@@ -60,7 +61,7 @@ def batched_script(path, out_path):
                 line = "prefill %s\n" % os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(path)), "..", "files", tok[1]))
             lines.append(line)
             if tok and (tok[0] == "create" or (tok[0] == "open" and tok[1] != "ro")):
-                lines.append("batch 1\n")
+                lines.append("batch %d\n" % mode)
     with open(out_path, "w") as f:
         f.writelines(lines)
     return out_path
