@@ -405,6 +405,20 @@ extern "C"
                                  uint64_t N_global,
                                  uint64_t offset_rows);
 
+    /* pgsd_write_chunks_device in two steps, for callers that know their device fields before they know the
+       frame's other chunks: pgsd_stage_chunks_device launches the fused pack AT ONCE (kernel and, for small
+       frames, the PCIe crossing then run under whatever the caller does next) and returns a ticket;
+       pgsd_write_staged_chunks writes chunks [first, first + count) of the ticket at THIS point of the frame's
+       chunk order -- same arguments, same exchange, same placement as pgsd_write_chunks_device, minus the
+       launch.  Chunks of a ticket that were never written are dropped by the next pgsd_end_frame / pgsd_close.
+       (For a simulation that can stage right behind its last kernel and has other work before the frame is
+       sealed.  pgsd.hoomd does NOT use it: staging ahead of its schema bookkeeping was measured and bought
+       nothing -- the extra call cost what the hidden kernel wait saved) */
+    int pgsd_stage_chunks_device(struct pgsd_handle* handle, uint32_t n_chunks, const struct pgsd_chunk_req* chunks,
+                                 uint64_t N, uint64_t* ticket);
+    int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                 uint64_t N_global, uint64_t offset_rows);
+
     /* Seal the frame like pgsd_end_frame, but do not wait for its device chunks: the frame
        counter advances and names / small-chunk buffers / index entries are committed now, while
        the device->host copies and the pwrite()s of the frame keep running behind the caller.

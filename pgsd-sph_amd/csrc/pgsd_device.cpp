@@ -478,12 +478,17 @@ class DevicePipeline
             bytes_out += bytes;
             }
 
-        // order the pack after whatever the caller enqueued on its source stream
-        hipEvent_t ready = get_event(false);
-        if (!ready)
-            return PGSD_ERROR_DEVICE;
-        HIP_TRY(hipEventRecord(ready, m_source_stream));
-        HIP_TRY(hipStreamWaitEvent(m_pack_stream, ready, 0));
+        // order the pack after whatever the caller enqueued on its source stream -- an event there and a wait
+        // here, unless that stream has nothing in flight (one query instead of two calls: small frames)
+        if (hipStreamQuery(m_source_stream) != hipSuccess)
+            {
+            (void)hipGetLastError(); // hipErrorNotReady is the answer, not an error
+            hipEvent_t ready = get_event(false);
+            if (!ready)
+                return PGSD_ERROR_DEVICE;
+            HIP_TRY(hipEventRecord(ready, m_source_stream));
+            HIP_TRY(hipStreamWaitEvent(m_pack_stream, ready, 0));
+            }
 
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (m_cfg.profile)
@@ -506,10 +511,17 @@ class DevicePipeline
             std::lock_guard<std::mutex> g(m_mutex);
             m_pack_events.push_back({ev0, ev1});
             }
-        hipEvent_t packed = get_event(false);
-        if (!packed)
-            return PGSD_ERROR_DEVICE;
-        HIP_TRY(hipEventRecord(packed, m_pack_stream));
+        // the event behind the launch: what the copies of a staged chunk wait for.  A direct launch is waited for
+        // with a stream synchronize by whoever writes it (drain, or the writer thread after an asynchronous
+        // seal), so it needs none
+        hipEvent_t packed = nullptr;
+        if (!direct)
+            {
+            packed = get_event(false);
+            if (!packed)
+                return PGSD_ERROR_DEVICE;
+            HIP_TRY(hipEventRecord(packed, m_pack_stream));
+            }
         std::lock_guard<std::mutex> g(m_mutex);
         m_stats.pack_launches++;
         m_stats.pack_rows += N;
@@ -557,13 +569,12 @@ class DevicePipeline
             if (host_dst)
                 {
                 // small replicated chunk headed for the write buffer: wait for the launch, plain memcpy
-                HIP_TRY(hipEventSynchronize(packed));
+                HIP_TRY(hipStreamSynchronize(m_pack_stream));
                 memcpy(host_dst, host, bytes);
                 return PGSD_SUCCESS;
                 }
             std::lock_guard<std::mutex> g(m_mutex);
             m_direct.push_back({host, bytes, file_offset});
-            m_direct_packed = packed;
             return PGSD_SUCCESS;
             }
         if (host_dst)
@@ -606,22 +617,21 @@ class DevicePipeline
     void kick_direct()
         {
         std::vector<DirectWrite> list;
-        hipEvent_t packed;
             {
             std::lock_guard<std::mutex> g(m_mutex);
             if (m_direct.empty())
                 return;
             list.swap(m_direct);
-            packed = m_direct_packed;
             m_outstanding += 1;
             }
         writer_pool_submit(m_pool,
-                           [this, list, packed]
+                           [this, list]
                            {
                                (void)hipSetDevice(m_cfg.device);
-                               hipError_t e = hipEventSynchronize(packed);
+                               // everything launched on the pack stream so far, these chunks' kernel included
+                               hipError_t e = hipStreamSynchronize(m_pack_stream);
                                if (e != hipSuccess)
-                                   fail(std::string("hipEventSynchronize(pack): ") + hipGetErrorString(e));
+                                   fail(std::string("hipStreamSynchronize(pack): ") + hipGetErrorString(e));
                                else
                                    write_direct(list);
                                piece_done(0, 0);
@@ -1413,7 +1423,6 @@ class DevicePipeline
     size_t m_dcap = 0, m_dused = 0, m_direct_max = 0;
     bool m_direct_failed = false;
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
-    hipEvent_t m_direct_packed = nullptr;  // pack event of the newest of them
     WriterPool* m_pool = nullptr;
     ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device
     std::atomic<bool> m_copy_used {false}; // something was enqueued on the copy stream since drain() last synchronised it

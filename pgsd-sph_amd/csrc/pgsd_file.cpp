@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <map>
 #include <string>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -160,6 +161,17 @@ struct Queued
     size_t ticket_index = 0;
     };
 
+// chunks packed ahead of their place in the frame (pgsd_stage_chunks_device)
+struct EarlyStage
+    {
+    int ticket = -1;
+    uint64_t N = 0;
+    int local_rc = PGSD_SUCCESS;
+    std::vector<std::string> names;
+    std::vector<uint32_t> types, Ms;
+    std::vector<bool> claimed;
+    };
+
 struct Impl
     {
     std::shared_ptr<CommBox> comm_box; // keeps the communicator alive for as long as the file is open
@@ -203,6 +215,8 @@ struct Impl
     bool defer_rows = false; // batched: host rows of all == true chunks stay valid until the exchange (pgsd_set_deferred_rows)
     bool unsynced = false; // a batched frame was sealed that no barrier between the ranks has covered yet
     std::vector<Queued> queue;
+    std::map<uint64_t, EarlyStage> early; // tickets of pgsd_stage_chunks_device not fully written yet
+    uint64_t next_early = 1;
 
     bool v1() const
         {
@@ -833,12 +847,27 @@ static int flush_for_lookup(Impl* s)
     return PGSD_SUCCESS;
     }
 
+// chunks that were staged ahead (pgsd_stage_chunks_device) and never written: their packed bytes go nowhere
+static void release_early(Impl* s)
+    {
+    for (auto& kv : s->early)
+        {
+        EarlyStage& e = kv.second;
+        for (size_t i = 0; i < e.claimed.size() && e.ticket >= 0 && s->dev; i++)
+            if (!e.claimed[i])
+                (void)device_pipeline_commit(s->dev, e.ticket, i, -1, nullptr, nullptr);
+        }
+    s->early.clear();
+    }
+
 static int do_end_frame(Impl* s, bool async = false)
     {
     // pgsd.c:1916-1953
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_ERROR_FILE_MUST_BE_WRITABLE;
     TraceRange tr("pgsd:end_frame frame=%llu", s->cur_frame);
+    if (!s->early.empty())
+        release_early(s);
     // queued chunks belong to the frame that is being sealed: place them before the counter moves
     const int qrc = s->queue.empty() ? PGSD_SUCCESS : resolve_queue(s);
     s->cur_frame++;
@@ -1458,6 +1487,8 @@ extern "C" int pgsd_close(struct pgsd_handle* handle)
     if (!s)
         return PGSD_ERROR_INVALID_ARGUMENT;
     int rc = PGSD_SUCCESS;
+    if (!s->early.empty())
+        release_early(s);
     if (s->flags != PGSD_OPEN_READONLY)
         {
         rc = do_flush(s);
@@ -1982,6 +2013,8 @@ extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pg
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (s->dev)
         {
+        if (!s->early.empty())
+            release_early(s);
         if (!s->queue.empty()) // packed chunks of the old pipeline still wait for their placement
             {
             int qrc = resolve_queue(s);
@@ -2213,6 +2246,151 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
             remember_failure(s, rc, 0);
             }
         }
+    publish(handle, s);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_stage_chunks_device(struct pgsd_handle* handle, uint32_t n_chunks, const struct pgsd_chunk_req* reqs,
+                                        uint64_t N, uint64_t* ticket_out)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s || !reqs || n_chunks == 0 || !ticket_out)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    *ticket_out = 0;
+    int local = PGSD_SUCCESS;
+    for (uint32_t i = 0; i < n_chunks && local == PGSD_SUCCESS; i++)
+        {
+        local = check_chunk_args(s, reqs[i].name, N, reqs[i].M, 0, N == 0 || reqs[i].src.src);
+        if (local == PGSD_SUCCESS && N > 0)
+            local = check_field(&reqs[i].src, reqs[i].type, reqs[i].M);
+        }
+    if (local == PGSD_SUCCESS)
+        local = ensure_device(s);
+    EarlyStage e;
+    e.N = N;
+    for (uint32_t i = 0; i < n_chunks; i++)
+        {
+        e.names.push_back(reqs[i].name ? reqs[i].name : "");
+        e.types.push_back(reqs[i].type);
+        e.Ms.push_back(reqs[i].M);
+        }
+    e.claimed.assign(n_chunks, false);
+    if (local == PGSD_SUCCESS)
+        {
+        std::vector<DeviceChunk> staged(n_chunks);
+        for (uint32_t i = 0; i < n_chunks; i++)
+            {
+            memset(&staged[i], 0, sizeof(DeviceChunk));
+            staged[i].job.dst_type = reqs[i].type;
+            staged[i].job.M = reqs[i].M;
+            staged[i].job.src = reqs[i].src;
+            staged[i].N = N;
+            }
+        std::string err;
+        local = device_pipeline_stage(s->dev, staged, N, &e.ticket, &err);
+        if (local != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            e.ticket = -1;
+            }
+        }
+    // a failed staging keeps its ticket too: every rank goes on to make the same pgsd_write_staged_chunks calls,
+    // which is where the other ranks learn of it
+    e.local_rc = local;
+    *ticket_out = s->next_early++;
+    s->early[*ticket_out] = std::move(e);
+    return local;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                        uint64_t N_global, uint64_t offset_rows)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s || count == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    auto it = s->early.find(ticket);
+    if (it == s->early.end() || (uint64_t)first + count > it->second.claimed.size())
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    EarlyStage& e = it->second;
+    for (uint32_t i = first; i < first + count; i++)
+        if (e.claimed[i])
+            return PGSD_ERROR_INVALID_ARGUMENT;
+    const int local = e.local_rc;
+    const uint64_t N = e.N;
+    int rc = local;
+    if (s->batch)
+        {
+        for (uint32_t i = first; i < first + count; i++)
+            {
+            Queued q;
+            q.name = e.names[i];
+            q.type = e.types[i];
+            q.N = N, q.M = e.Ms[i], q.N_global = N_global, q.M_global = e.Ms[i];
+            q.offset = offset_rows * e.Ms[i];
+            q.all = true;
+            q.local_rc = local;
+            q.ticket = e.ticket;
+            q.ticket_index = i;
+            s->queue.push_back(std::move(q));
+            }
+        }
+    else
+        {
+        // one exchange for the chunks of the call (they share the row count), then placement and hand-over
+        std::vector<uint64_t> rows;
+        rc = exchange_counts(s, N, local, rows);
+        if (rc == PGSD_SUCCESS && N_global == PGSD_PARTITION_AUTO)
+            {
+            uint64_t off_elems = 0;
+            auto_partition(s, rows, 1, 1, &N_global, &off_elems);
+            offset_rows = off_elems;
+            }
+        std::vector<uint64_t> sizes((size_t)s->P);
+        for (uint32_t i = first; i < first + count; i++)
+            {
+            Placement pl;
+            memset(&pl, 0, sizeof(pl));
+            int prc = rc;
+            if (prc == PGSD_SUCCESS)
+                {
+                for (int r = 0; r < s->P; r++)
+                    sizes[(size_t)r] = rows[(size_t)r] * e.Ms[i] * sizeof_type(e.types[i]);
+                prc = place_chunk(s, e.names[i].c_str(), e.types[i], N, e.Ms[i], N_global, e.Ms[i], offset_rows * e.Ms[i],
+                                  true, sizes, &pl);
+                }
+            if (e.ticket >= 0)
+                {
+                std::string err;
+                const bool skip = prc != PGSD_SUCCESS || pl.size == 0;
+                int drc = device_pipeline_commit(s->dev, e.ticket, i, skip ? -1 : pl.file_offset, nullptr, &err);
+                if (drc != PGSD_SUCCESS && prc == PGSD_SUCCESS)
+                    {
+                    set_last_error(err);
+                    remember_failure(s, drc, 0);
+                    prc = drc;
+                    }
+                }
+            if (prc != PGSD_SUCCESS && rc == PGSD_SUCCESS)
+                rc = prc;
+            }
+        }
+    for (uint32_t i = first; i < first + count; i++)
+        e.claimed[i] = true;
+    bool all_claimed = true;
+    for (bool c : e.claimed)
+        all_claimed = all_claimed && c;
+    if (all_claimed)
+        s->early.erase(it);
     publish(handle, s);
     return rc;
     }

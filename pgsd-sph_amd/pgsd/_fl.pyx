@@ -674,6 +674,60 @@ cdef class PGSDFile:
             free(reqs)
         _raise_on_error(retval, self._name, err)
 
+    def stage_chunks(self, fields):
+        """Launch the fused pack of ``fields`` (as in :meth:`write_chunks`) NOW and return a ticket; the chunks get
+        their place in the frame later, with :meth:`write_staged` (``pgsd_stage_chunks_device``).  The kernel -- and
+        for small frames the PCIe crossing -- then runs under whatever the caller does in between."""
+        self._check_open()
+        if not self._explicit_stream:
+            self._sync_source_stream()
+        cdef Py_ssize_t n = len(fields), i
+        if n == 0:
+            raise ValueError("no fields to stage")
+        cdef C.pgsd_chunk_req* reqs = <C.pgsd_chunk_req*>calloc(n, sizeof(C.pgsd_chunk_req))
+        if reqs == NULL:
+            raise MemoryError()
+        cdef DeviceField f
+        cdef uint64_t N = 0, ticket = 0
+        cdef int retval, err
+        names = []
+        try:
+            for i in range(n):
+                name, data = fields[i]
+                f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
+                if i == 0:
+                    N = f.N
+                elif <uint64_t>f.N != N:
+                    raise ValueError("all fields of a fused write must have the same number of rows")
+                name_b = name.encode('utf-8')
+                names.append(name_b)
+                reqs[i].name = name_b
+                reqs[i].type = f.out_type(name)
+                reqs[i].M = <uint32_t>f.M
+                f.fill_desc(&reqs[i].src)
+                self._keepalive.append(f)
+            with nogil:
+                retval = C.pgsd_stage_chunks_device(&self._handle, <uint32_t>n, reqs, N, &ticket)
+                err = errno
+        finally:
+            free(reqs)
+        _raise_on_error(retval, self._name, err)
+        return (int(ticket), int(N))
+
+    def write_staged(self, ticket, first, count, offset=None, rank=0):
+        """Write chunks ``[first, first + count)`` of a :meth:`stage_chunks` ticket at this point of the frame
+        (``offset`` / ``rank`` as in :meth:`write_chunks`)."""
+        self._check_open()
+        cdef uint64_t c_ticket = ticket[0], N = ticket[1], N_global, row0
+        cdef uint32_t c_first = first, c_count = count
+        py_ng, py_row0 = self._partition_args(offset, rank, N, 1)
+        N_global, row0 = py_ng, py_row0
+        cdef int retval, err
+        with nogil:
+            retval = C.pgsd_write_staged_chunks(&self._handle, c_ticket, c_first, c_count, N_global, row0)
+            err = errno
+        _raise_on_error(retval, self._name, err)
+
     def wait_packed(self):
         """Block until the pack kernels of the open frame are done (sources may be reused)."""
         cdef int retval

@@ -174,6 +174,10 @@ cdef extern from "pgsd.h" nogil:
                                 uint8_t flags, const pgsd_field_desc* src)
     int pgsd_write_chunks_device(pgsd_handle* handle, uint32_t n_chunks, const pgsd_chunk_req* chunks, uint64_t N,
                                  uint64_t N_global, uint64_t offset_rows)
+    int pgsd_stage_chunks_device(pgsd_handle* handle, uint32_t n_chunks, const pgsd_chunk_req* chunks, uint64_t N,
+                                 uint64_t* ticket)
+    int pgsd_write_staged_chunks(pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                 uint64_t N_global, uint64_t offset_rows)
     int pgsd_end_frame_async(pgsd_handle* handle)
     int pgsd_frame_sync(pgsd_handle* handle)
     int pgsd_device_wait_packed(pgsd_handle* handle)

@@ -306,3 +306,50 @@ def test_odd_pipeline_geometries_write_the_same_bytes(slab_bytes, n_slabs, write
         if slab_bytes < (1 << 20):
             f.configure_device(slab_bytes=slab_bytes, n_slabs=n_slabs)
         np.testing.assert_array_equal(f.read_chunk_device(1, 'particles/image').cpu().numpy(), img)
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_stage_now_write_later(batched, tmp_path):
+    """pgsd_stage_chunks_device / pgsd_write_staged_chunks: the fused pack is launched at once, the chunks take their
+    places in the frame later, in whatever order and grouping the caller writes them -- with host chunks in between
+    -- and a staged chunk that is never written is dropped at end_frame.  The file equals the oracle's for the
+    sequence actually written."""
+    import pgsd.fl as fl
+    from test_gpu_file import _oracle_frames
+    rng = np.random.default_rng(21)
+    mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
+    f = fl.open(mine, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+    f.frame_exchange = batched
+    frames = []
+    for frame, N in enumerate([1000, 150_000, 0, 7]):
+        pos4 = G.rand_array(rng, (N, 4), np.float32)
+        vel4 = G.rand_array(rng, (N, 4), np.float64)
+        img = rng.integers(-3, 4, size=(N, 3)).astype(np.int32)
+        dpos, dvel, dimg = dev(pos4), dev(vel4), dev(img)
+        ticket = f.stage_chunks([("particles/position", fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
+                                 ("particles/velocity", fl.DeviceField.from_tensor(dvel, columns=(0, 3), out_dtype=np.float32)),
+                                 ("particles/image", dimg),
+                                 ("particles/never_written", fl.DeviceField.from_tensor(dpos, columns=(3, 4)))])
+        step = np.array([frame], dtype=np.uint64)
+        host = G.rand_array(rng, (N, 2), np.float32)
+        f.write_chunk("configuration/step", step, write_all=False)
+        f.write_staged(ticket, 1, 2, offset=np.array([N]))              # velocity, image
+        f.write_chunk("particles/host_field", host, offset=np.array([N]))
+        f.write_staged(ticket, 0, 1, offset=np.array([N]))              # position, after them
+        with pytest.raises(RuntimeError):
+            f.write_staged(ticket, 0, 1, offset=np.array([N]))          # already written
+        f.end_frame()                                                   # drops `never_written`
+        with pytest.raises(RuntimeError):
+            f.write_staged(ticket, 3, 1, offset=np.array([N]))          # the ticket died with the frame
+        frames.append([("configuration/step", 4, 1, False, [step.reshape(1, 1)]),
+                       ("particles/velocity", 9, 3, True, [G.oracle_pack(vel4, 3, out_dtype=np.float32)]),
+                       ("particles/image", 7, 3, True, [img]),
+                       ("particles/host_field", 9, 2, True, [host]),
+                       ("particles/position", 9, 3, True, [G.oracle_pack(pos4, 3)])])
+    f.close()
+    _oracle_frames(ref, 1, frames)
+    with open(mine, 'rb') as a, open(ref, 'rb') as b:
+        assert a.read() == b.read()
+    g = fl.open(mine, 'r')
+    assert not g.chunk_exists(0, "particles/never_written") and g.nframes == 4
+    g.close()

@@ -25,7 +25,8 @@ def frame(i):
     f.particles.N = N
     f.configuration.step = i
     if host:
-        pos[0, 0] = i
+        pos[0, 0] = i       # both arrays differ from frame 0 every frame: nothing is elided (device arrays never are)
+        ori[0, 0] = i
     f.particles.position = pos
     f.particles.orientation = ori
     return f

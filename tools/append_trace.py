@@ -27,7 +27,9 @@ def frame(i):
     f = H.Frame()
     f.particles.N = N
     f.configuration.step = i
-    pos[0, 0] = i
+    if host:
+        pos[0, 0] = i       # both arrays differ from frame 0 every frame: nothing is elided (device arrays never are)
+        ori[0, 0] = i
     f.particles.position = pos
     f.particles.orientation = ori
     return f
