@@ -222,6 +222,23 @@ extern "C"
        frame's exchange.  Collective like pgsd_end_frame when it turns batching off. */
     int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched);
     int pgsd_get_frame_exchange(struct pgsd_handle* handle);
+    /* Declared partition: NO exchange per chunk and none per frame.  The caller tells the library every rank's
+       row count -- what a size exchange would tell it -- because it has exchanged the counts itself (pgsd.hoomd's
+       one allgather per frame carries them next to its write/skip votes) or because they have not changed since
+       the last snapshot (a run without particle migration writes frame after frame with ZERO collectives).  While a
+       partition is declared:
+         - a chunk written with N_global == PGSD_PARTITION_AUTO is partitioned by it: N must be rows[rank]; the
+           global row count is the sum, this rank's first row the prefix;
+         - any other chunk must have the same byte size on every rank (replicated data, or data every rank writes
+           alike: the reference binding's default-argument call shape);
+       and every chunk is placed at once from that knowledge, byte for byte where the exchanges would have put it
+       (every golden and fuzz scenario is replayed this way).  Errors: a call that fails this rank's checks returns
+       the code at once; the other ranks learn of it at the next synchronisation point (pgsd_flush / pgsd_close / a
+       read), like a failed write; the frame's barrier is made up there too, as with the batched exchange.
+       rows == NULL clears the declaration.  Every rank must declare the same vector (n_ranks = the communicator's
+       size). */
+    int pgsd_set_partition(struct pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks);
+
     /* Batched mode only: with `on`, the host rows of pgsd_write_chunk(..., all == true, data) are BORROWED UNTIL
        THE FRAME'S EXCHANGE instead of for the call -- the caller promises to leave them alone until the next
        pgsd_end_frame / pgsd_flush / pgsd_frame_exchange / pgsd_close (the contract device sources have anyway).

@@ -215,6 +215,10 @@ struct Impl
     bool defer_rows = false; // batched: host rows of all == true chunks stay valid until the exchange (pgsd_set_deferred_rows)
     bool unsynced = false; // a batched frame was sealed that no barrier between the ranks has covered yet
     std::vector<Queued> queue;
+    // declared partition (pgsd_set_partition): every rank's row count is known, chunk writes exchange nothing
+    std::vector<uint64_t> partition;
+    bool have_partition = false;
+    bool poisoned = false; // a call failed on this rank where the other ranks went on: this rank stops writing
     std::map<uint64_t, EarlyStage> early; // tickets of pgsd_stage_chunks_device not fully written yet
     uint64_t next_early = 1;
 
@@ -794,7 +798,7 @@ static int do_flush(Impl* s, bool async = false, bool sync_point = true)
     s->meta_async = false;
     if (sticky_errno)
         errno = sticky_errno;
-    if (s->batch && !sync_point && s->P > 1)
+    if ((s->batch || s->have_partition) && !sync_point && s->P > 1)
         {
         // batched frame exchange: no second collective per frame.  This rank's verdict is returned now
         // and travels to the others with the next exchange; the barrier that guarantees every rank's
@@ -874,7 +878,7 @@ static int do_end_frame(Impl* s, bool async = false)
     s->pending = 0;
     int rc = PGSD_SUCCESS;
     if (!s->frame_index.empty() || s->buffer_index.size() > s->idxbuf)
-        rc = do_flush(s, async, !s->batch);
+        rc = do_flush(s, async, !(s->batch || s->have_partition));
     return qrc != PGSD_SUCCESS ? qrc : rc;
     }
 
@@ -1290,6 +1294,71 @@ static int resolve_queue(Impl* s)
         }
     return first_rc;
     }
+// Declared partition (pgsd_set_partition): every rank's byte count of a chunk follows from what the caller
+// declared, so the chunk is placed without an exchange.  N_global == PGSD_PARTITION_AUTO: the chunk is
+// partitioned by the declared rows (this rank must bring exactly its share); anything else must have the same
+// size on every rank (replicated data; the default-argument call shape).  The placement is what place_chunk
+// computes from those sizes, i.e. what the exchanges would have produced.
+// `local`: this rank's argument / device verdict.  The other ranks cannot be told now, and they WILL place the
+// chunk: so does this rank whenever it can (state stays in step, the rows are simply missing), and the failure
+// is remembered for the next synchronisation point; when it cannot (no name, M == 0) the handle is poisoned.
+static int trusted_place(Impl* s, const char* name, uint32_t type, uint64_t N, uint32_t M, uint64_t* N_global,
+                         uint32_t M_global, uint64_t* offset, bool all, int local, Placement* pl, bool* deliver)
+    {
+    *deliver = false;
+    memset(pl, 0, sizeof(*pl));
+    if (s->poisoned)
+        return s->sticky_rc != PGSD_SUCCESS ? s->sticky_rc : PGSD_ERROR_INVALID_ARGUMENT;
+    const uint64_t unit = (uint64_t)M * sizeof_type(type);
+    if (!name || unit == 0 || s->flags == PGSD_OPEN_READONLY)
+        {
+        if (s->flags != PGSD_OPEN_READONLY)
+            {
+            s->poisoned = true; // the other ranks place a chunk this rank cannot even size
+            remember_failure(s, local != PGSD_SUCCESS ? local : PGSD_ERROR_INVALID_ARGUMENT, 0);
+            }
+        return local != PGSD_SUCCESS ? local : PGSD_ERROR_INVALID_ARGUMENT;
+        }
+    std::vector<uint64_t> sizes((size_t)s->P);
+    if (*N_global == PGSD_PARTITION_AUTO)
+        {
+        uint64_t total = 0, before = 0;
+        for (int r = 0; r < s->P; r++)
+            {
+            sizes[(size_t)r] = s->partition[(size_t)r] * unit;
+            if (r < s->rank)
+                before += s->partition[(size_t)r];
+            total += s->partition[(size_t)r];
+            }
+        *N_global = total;
+        *offset = before * M;
+        if (N != s->partition[(size_t)s->rank] && local == PGSD_SUCCESS)
+            {
+            set_last_error("pgsd_set_partition declared another row count for this rank than the chunk brings");
+            local = PGSD_ERROR_INVALID_ARGUMENT;
+            }
+        }
+    else
+        for (int r = 0; r < s->P; r++)
+            sizes[(size_t)r] = N * unit;
+    // place with the DECLARED size of this rank, so that the replicated state moves as on the other ranks
+    const uint64_t n_declared = sizes[(size_t)s->rank] / unit;
+    int rc = place_chunk(s, name, type, n_declared, M, *N_global, M_global, *offset, all, sizes, pl);
+    if (rc != PGSD_SUCCESS)
+        {
+        // name list full etc.: replicated state, every rank fails alike
+        return rc;
+        }
+    if (local != PGSD_SUCCESS)
+        {
+        remember_failure(s, local, errno);
+        if (pl->buffered) // the buffer must keep the length every rank has accounted for
+            s->write_buffer.insert(s->write_buffer.end(), pl->size, 0);
+        return local;
+        }
+    *deliver = true;
+    return PGSD_SUCCESS;
+    }
     } // namespace pgsd_amd
 
 using namespace pgsd_amd;
@@ -1589,6 +1658,31 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
         return PGSD_ERROR_INVALID_ARGUMENT;
     (void)global_size; // dead in the reference as well (pgsd.c:2147-2151)
     const int local = check_chunk_args(s, name, N, M, flags, data != NULL);
+    if (s->have_partition)
+        {
+        // declared partition: no exchange, placed and written at once
+        Placement pl;
+        bool deliver = false;
+        int rc = trusted_place(s, name, (uint32_t)type, N, M, &N_global, M_global, &offset, all, local, &pl, &deliver);
+        if (deliver && pl.size > 0)
+            {
+            if (pl.buffered)
+                s->write_buffer.insert(s->write_buffer.end(), (const char*)data, (const char*)data + pl.size);
+            else if (pl.write)
+                {
+                TraceRange tr("pgsd:pwrite_host file_off=%llu bytes=%llu", (unsigned long long)pl.file_offset, pl.size);
+                int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
+                if (e != 0)
+                    {
+                    errno = -e;
+                    rc = PGSD_ERROR_IO;
+                    remember_failure(s, rc, -e);
+                    }
+                }
+            }
+        publish(handle, s);
+        return rc;
+        }
     if (s->batch)
         {
         // frame-batched exchange: a replicated chunk (all == false) waits, with a copy of its rows, for
@@ -1924,6 +2018,33 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
+extern "C" int pgsd_set_partition(struct pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s || (rows && n_ranks != (uint32_t)s->P))
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = PGSD_SUCCESS;
+    if (!s->queue.empty()) // chunks queued under the batched exchange are placed by it, before the rules change
+        rc = resolve_queue(s);
+    if (rows)
+        {
+        s->partition.assign(rows, rows + n_ranks);
+        s->have_partition = true;
+        }
+    else
+        {
+        s->partition.clear();
+        s->have_partition = false;
+        }
+    publish(handle, s);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
 extern "C" int pgsd_set_deferred_rows(struct pgsd_handle* handle, int on)
     try
     {
@@ -2074,6 +2195,44 @@ extern "C" int pgsd_write_chunk_device(struct pgsd_handle* handle, const char* n
         local = check_field(src, (uint32_t)type, M);
     if (local == PGSD_SUCCESS)
         local = ensure_device(s);
+    if (s->have_partition)
+        {
+        Placement pl;
+        bool deliver = false;
+        int rc = trusted_place(s, name, (uint32_t)type, N, M, &N_global, M_global, &offset, all, local, &pl, &deliver);
+        if (deliver && pl.size > 0 && (pl.buffered || pl.write))
+            {
+            std::vector<DeviceChunk> chunks(1);
+            DeviceChunk& c = chunks[0];
+            memset(&c, 0, sizeof(c));
+            c.job.dst_type = (uint32_t)type;
+            c.job.M = M;
+            c.job.src = *src;
+            c.N = N;
+            std::vector<char> tmp;
+            if (pl.buffered)
+                {
+                tmp.resize(pl.size);
+                c.file_offset = -1;
+                c.host_dst = tmp.data();
+                }
+            else
+                c.file_offset = pl.file_offset;
+            std::string err;
+            rc = device_pipeline_submit(s->dev, chunks, N, &err);
+            if (rc != PGSD_SUCCESS)
+                {
+                set_last_error(err);
+                remember_failure(s, rc, 0);
+                if (pl.buffered)
+                    s->write_buffer.insert(s->write_buffer.end(), pl.size, 0);
+                }
+            else if (pl.buffered)
+                s->write_buffer.insert(s->write_buffer.end(), tmp.begin(), tmp.end());
+            }
+        publish(handle, s);
+        return rc;
+        }
     if (s->batch)
         {
         // pack now (the kernel needs no file offset), place at the frame's exchange
@@ -2166,6 +2325,47 @@ extern "C" int pgsd_write_chunks_device(struct pgsd_handle* handle, uint32_t n_c
         }
     if (local == PGSD_SUCCESS)
         local = ensure_device(s);
+    if (s->have_partition)
+        {
+        // declared partition: every chunk placed now, ONE fused launch, copies and writes start at once
+        std::vector<DeviceChunk> chunks;
+        int rc = PGSD_SUCCESS;
+        for (uint32_t i = 0; i < n_chunks; i++)
+            {
+            Placement pl;
+            bool deliver = false;
+            uint64_t ng = N_global, off = offset_rows * reqs[i].M;
+            int prc = trusted_place(s, reqs[i].name, reqs[i].type, N, reqs[i].M, &ng, reqs[i].M, &off, true, local, &pl,
+                                    &deliver);
+            if (prc != PGSD_SUCCESS && rc == PGSD_SUCCESS)
+                rc = prc;
+            if (deliver && pl.size > 0)
+                {
+                DeviceChunk c;
+                memset(&c, 0, sizeof(c));
+                c.job.dst_type = reqs[i].type;
+                c.job.M = reqs[i].M;
+                c.job.src = reqs[i].src;
+                c.N = N;
+                c.file_offset = pl.file_offset;
+                chunks.push_back(c);
+                }
+            }
+        if (!chunks.empty())
+            {
+            std::string err;
+            int drc = device_pipeline_submit(s->dev, chunks, N, &err);
+            if (drc != PGSD_SUCCESS)
+                {
+                set_last_error(err);
+                remember_failure(s, drc, 0);
+                if (rc == PGSD_SUCCESS)
+                    rc = drc;
+                }
+            }
+        publish(handle, s);
+        return rc;
+        }
     if (s->batch)
         {
         // one fused pack launch now, placement of every chunk at the frame's exchange
@@ -2328,7 +2528,33 @@ extern "C" int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t tic
     const int local = e.local_rc;
     const uint64_t N = e.N;
     int rc = local;
-    if (s->batch)
+    if (s->have_partition)
+        {
+        rc = PGSD_SUCCESS;
+        for (uint32_t i = first; i < first + count; i++)
+            {
+            Placement pl;
+            bool deliver = false;
+            uint64_t ng = N_global, off = offset_rows * e.Ms[i];
+            int prc = trusted_place(s, e.names[i].c_str(), e.types[i], N, e.Ms[i], &ng, e.Ms[i], &off, true, local, &pl,
+                                    &deliver);
+            if (e.ticket >= 0)
+                {
+                std::string err;
+                const bool skip = !deliver || pl.size == 0;
+                int drc = device_pipeline_commit(s->dev, e.ticket, i, skip ? -1 : pl.file_offset, nullptr, &err);
+                if (drc != PGSD_SUCCESS && prc == PGSD_SUCCESS)
+                    {
+                    set_last_error(err);
+                    remember_failure(s, drc, 0);
+                    prc = drc;
+                    }
+                }
+            if (prc != PGSD_SUCCESS && rc == PGSD_SUCCESS)
+                rc = prc;
+            }
+        }
+    else if (s->batch)
         {
         for (uint32_t i = first; i < first + count; i++)
             {

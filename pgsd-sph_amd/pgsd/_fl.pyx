@@ -477,6 +477,28 @@ cdef class PGSDFile:
         _raise_on_error(retval, self._name, err)
         self._deferred_rows = bool(on)
 
+    def set_partition(self, rows):
+        """Declare every rank's row count (``pgsd_set_partition``): while declared, chunk writes exchange nothing --
+        chunks written with ``offset='auto'`` are partitioned by ``rows`` (this rank must bring ``rows[rank]``),
+        every other chunk must have the same size on every rank -- and a frame costs no collective at all.
+        ``None`` clears the declaration.  Every rank must declare the same vector."""
+        cdef int retval, err
+        cdef uint32_t n = 0
+        cdef const uint64_t[::1] view
+        cdef const uint64_t* ptr = NULL
+        self._check_open()
+        if rows is not None:
+            arr = numpy.ascontiguousarray(rows, dtype=numpy.uint64)
+            if arr.ndim != 1 or arr.shape[0] != self._handle.nprocs:
+                raise ValueError("the partition must have one row count per rank")
+            view = arr
+            ptr = &view[0]
+            n = arr.shape[0]
+        with nogil:
+            retval = C.pgsd_set_partition(&self._handle, ptr, n)
+            err = errno
+        _raise_on_error(retval, self._name, err)
+
     def exchange_now(self):
         """Perform the pending frame exchange now (collective; nothing is flushed)."""
         cdef int retval, err

@@ -383,15 +383,14 @@ class HOOMDTrajectory(object):
                     if self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
                         self._frame0_chunks.add(path + '/' + name)
 
-        # From here on the frame costs two collectives however many chunks of whatever kind it has: the
-        # allgather below (row counts + write/skip votes) and the one frame exchange of end_frame, which places
-        # every queued chunk (pgsd_set_frame_exchange; the file is byte-identical to the unbatched one).  Host
-        # arrays wait for that exchange too (deferred_rows: this method holds them until end_frame returns)
-        # instead of forcing an exchange each, and so do state/* and log/* chunks.
-        if getattr(self.file, 'frame_exchange', None) is False:
+        # From here on the frame costs ONE collective however many chunks of whatever kind it has: the allgather
+        # below (every rank's row count + its write/skip votes).  With the counts in hand the partition is DECLARED
+        # to the library (pgsd_set_partition), which then places every chunk without an exchange of its own:
+        # per-particle chunks by the declared rows (offset='auto'), everything else -- replicated small chunks,
+        # state/* and log/* -- has the same size on every rank.  The file is byte-identical to the one the
+        # exchanges would produce.  (One rank: nothing to exchange, the batched queue keeps the call pattern.)
+        if size == 1 and getattr(self.file, 'frame_exchange', None) is False:
             self.file.frame_exchange = True
-        if getattr(self.file, 'deferred_rows', None) is False:
-            self.file.deferred_rows = True
 
         # 1. decide locally which chunks to write, then ONE allgather carries every rank's particle count
         #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes
@@ -429,6 +428,12 @@ class HOOMDTrajectory(object):
         n_global = int(part_dist.sum())
         plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') and w else w)
                 for p, n, w in plan]
+        declared = size > 1 and hasattr(self.file, 'set_partition')
+        if declared:
+            if int(part_dist[rank]) != n_local:
+                raise ValueError("part_dist[%d] = %d but this rank holds %d particles" % (rank, int(part_dist[rank]), n_local))
+            self.file.set_partition(part_dist)
+        particle_offset = 'auto' if declared else part_dist
 
         # 2. write, in the reference's chunk order; device fields go out in one fused launch
         device_fields = []
@@ -450,10 +455,10 @@ class HOOMDTrajectory(object):
                     f = data if isinstance(data, fl.DeviceField) else fl.DeviceField.from_tensor(data, out_dtype=dt)
                     device_fields.append((chunk, f))
                 else:
-                    self._flush_device_fields(device_fields, part_dist, rank)
-                    self.file.write_chunk(chunk, data, part_dist, rank, True)
+                    self._flush_device_fields(device_fields, particle_offset, rank)
+                    self.file.write_chunk(chunk, data, particle_offset, rank, True)
                 continue
-            self._flush_device_fields(device_fields, part_dist, rank)
+            self._flush_device_fields(device_fields, particle_offset, rank)
             # replicated small chunks (hoomd.py:604-630)
             if name == 'N':
                 count = n_global if path == 'particles' else int(container.N)
@@ -467,7 +472,7 @@ class HOOMDTrajectory(object):
                     data = [json.dumps(shape_dict) for shape_dict in data]
                 data = _encode_strings(data)
             self.file.write_chunk(chunk, data, None, rank, False)
-        self._flush_device_fields(device_fields, part_dist, rank)
+        self._flush_device_fields(device_fields, particle_offset, rank)
 
         # state and logged quantities: the sketch calls ``write_chunk(name, data)`` with the binding's
         # default arguments (hoomd.py:634-640; the state loop is commented out twice, upstream GSD
@@ -479,6 +484,8 @@ class HOOMDTrajectory(object):
             self.file.write_chunk('log/' + log, data)
 
         self.file.end_frame(wait=wait)
+        if declared:
+            self.file.set_partition(None)       # the declaration was this frame's
 
     def _flush_device_fields(self, device_fields, part_dist, rank):
         if device_fields:

@@ -43,8 +43,12 @@
  *   chunkgs <name> <type> <M> <all> <dist> <global_size>
  *         (as chunk, but the caller's global_size argument is the given value, right or wrong:
  *          the reference ignores it, pgsd.c:2147-2151, 2240-2246)
- *   batch <0|1|2>                  (product only: pgsd_set_frame_exchange; 2 = batched + pgsd_set_deferred_rows: the
+ *   batch <0|1|2|3>                (product only: pgsd_set_frame_exchange; 2 = batched + pgsd_set_deferred_rows: the
  *                                   driver then keeps every chunk's rows until the next end_frame / flush / close / dump;
+ *                                   3 = declared partition: before every `chunk` the driver calls pgsd_set_partition
+ *                                   with that chunk's row counts and writes per-particle chunks with
+ *                                   PGSD_PARTITION_AUTO -- no exchange; chunks whose sizes the declaration cannot
+ *                                   express (chunkgs / rawchunk / samechunk, replicated chunks of unequal size) clear it;
  *                                   ignored by the reference build.
  *                                   `dump` then performs the pending exchange first, so that the trace
  *                                   shows the same file_size the unbatched run shows)
@@ -237,6 +241,7 @@ static enum pgsd_open_flag parse_flag(const char* s)
 
 /* rows of chunk writes that must outlive the call (batch 2: pgsd_set_deferred_rows): freed at the next
    end_frame / flush / close / dump, all of which resolve the queue */
+static int g_trusted = 0; /* batch 3 */
 static void* g_kept[65536];
 static int g_nkept = 0;
 static int g_defer = 0;
@@ -353,6 +358,23 @@ int main(int argc, char** argv)
                     row0 += counts[r];
                 }
             void* data;
+#ifndef PGSD_DRIVER_REF
+            if (g_trusted)
+                {
+                /* a replicated chunk must have one size on all ranks for the declaration to cover it */
+                int same = 1;
+                for (int r = 1; r < g_size; r++)
+                    same = same && counts[r] == counts[0];
+                pgsd_set_partition(&handle, (all || same) ? counts : NULL, (uint32_t)g_size);
+                }
+            if (g_trusted && all)
+                {
+                data = gen_data(type, seed, row0, N, M, sz);
+                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, PGSD_PARTITION_AUTO, M, 0, 0, true, 0,
+                                      data);
+                }
+            else
+#endif
             if (all)
                 {
                 data = gen_data(type, seed, row0, N, M, sz);
@@ -384,6 +406,10 @@ int main(int argc, char** argv)
                     row0 += counts[r];
                 }
             void* data = gen_data(type, seed, row0, N, M, sz);
+#ifndef PGSD_DRIVER_REF
+            if (g_trusted)
+                pgsd_set_partition(&handle, NULL, 0);
+#endif
             rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M, gs, all != 0, 0,
                                   data);
             release_rows(data);
@@ -400,6 +426,10 @@ int main(int argc, char** argv)
             uint64_t gs = strtoull(tok[8], NULL, 10);
             int all = atoi(tok[9]);
             void* data = gen_data(type, cmd[0] == 's' ? seed : seed + (uint64_t)g_rank, 0, N, M, sz);
+#ifndef PGSD_DRIVER_REF
+            if (g_trusted)
+                pgsd_set_partition(&handle, NULL, 0);
+#endif
             rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, Mg, off, gs,
                                   all != 0, 0, data);
             release_rows(data);
@@ -426,7 +456,11 @@ int main(int argc, char** argv)
         else if (strcmp(cmd, "batch") == 0 && nt == 2)
             {
 #ifndef PGSD_DRIVER_REF
-            rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]) != 0);
+            g_trusted = atoi(tok[1]) == 3;
+            if (g_trusted)
+                rc = 0;
+            else
+                rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]) != 0);
             if (rc == 0 && atoi(tok[1]) == 2)
                 {
                 rc = pgsd_set_deferred_rows(&handle, 1);

@@ -326,10 +326,11 @@ def test_bad_arguments_on_one_rank_fail_the_call_everywhere_without_a_hang(batch
     assert r1[1] == -2 and (r0[1] == -2 or r0[2] == -2)
 
 
-def test_hoomd_append_costs_two_collectives_per_frame_for_host_arrays_too(mirror, tmp_path):
-    """`HOOMDTrajectory.append` at P > 1: the row-count / vote allgather and ONE frame exchange, however many host
-    arrays, state and log chunks the frame holds (round 2: every host per-particle chunk and every log chunk forced
-    an exchange of its own -- ADVICE r2).  The arrays wait for the exchange (`deferred_rows`)."""
+def test_hoomd_append_costs_one_collective_per_frame(mirror, tmp_path):
+    """`HOOMDTrajectory.append` at P > 1: ONE collective per frame -- its own allgather of row counts and write/skip
+    votes -- however many host arrays, state and log chunks the frame holds: with the counts in hand the partition is
+    declared to the library (`pgsd_set_partition`), which places every chunk without an exchange of its own.
+    (Round 2: two, plus one per host per-particle chunk and per log chunk.)"""
     import pgsd.hoomd as hoomd
     t = hoomd.open(str(tmp_path / "h.gsd"), "w")
     rng = np.random.default_rng(1)
@@ -348,11 +349,65 @@ def test_hoomd_append_costs_two_collectives_per_frame_for_host_arrays_too(mirror
         n0 = len(mirror.calls)
         t.append(fr)
         per_frame.append(len(mirror.calls) - n0)
-    assert t.file.deferred_rows and t.file.frame_exchange
     # (the second append reads frame 0 back as its elision reference: a read is a synchronisation point and
-    # makes up the barrier the batched frame 0 skipped -- once per trajectory)
-    assert per_frame == [2, 3, 2, 2], per_frame
+    # makes up the barrier the frames before it skipped -- once per trajectory)
+    assert per_frame == [1, 2, 1, 1], per_frame
     t.close()
     with hoomd.open(str(tmp_path / "h.gsd"), "r") as r:
         assert len(r) == 4 and r[3].particles.N == 100                 # the mirrored peer wrote the same rows
         assert r[2].log["energy"][0] == 3.0
+
+
+def test_declared_partition_frames_cost_no_collective_and_match_the_exchanged_file(mirror, tmp_path):
+    """`pgsd_set_partition`: the caller declares every rank's row count once; frames of replicated chunks,
+    per-particle host arrays (offset='auto') and default-argument chunks are then placed with NO exchange, and the file
+    is the one the per-chunk exchanges produce."""
+    rng = np.random.default_rng(2)
+    data = [(rng.random((7, 3), dtype=np.float32), rng.integers(0, 5, size=7).astype(np.uint32), rng.random(4)) for _ in range(3)]
+    paths = []
+    for declared in (False, True):
+        p = str(tmp_path / ("d%d.gsd" % declared))
+        f = fl.open(p, "w", application="app", schema="hoomd", schema_version=[1, 4])
+        if declared:
+            f.set_partition([7, 7])                     # the mirrored peer brings the same rows
+        per_frame = []
+        for i, (pos, tid, log) in enumerate(data):
+            n0 = len(mirror.calls)
+            small_frame(f, i)
+            f.write_chunk("particles/position", pos, offset="auto" if declared else np.array([7, 7]), rank=0)
+            f.write_chunk("particles/typeid", tid, offset="auto" if declared else np.array([7, 7]), rank=0)
+            f.write_chunk("log/virial", log)            # default arguments: every rank writes the same rows
+            f.end_frame()
+            per_frame.append(len(mirror.calls) - n0)
+        assert per_frame == ([0, 0, 0] if declared else [7, 7, 7]), per_frame
+        if declared:
+            f.set_partition(None)
+        f.close()
+        paths.append(p)
+    with open(paths[0], "rb") as a, open(paths[1], "rb") as b:
+        assert a.read() == b.read()
+    g = fl.open(paths[0], "r")
+    assert g.nframes == 3 and g.read_chunk(2, "particles/position").shape == (14, 3)
+    g.close()
+
+
+def test_declared_partition_refuses_another_share_at_once_and_reports_it_at_the_next_sync(mirror, tmp_path):
+    """A chunk that does not bring this rank's declared share is refused by the call itself; the other ranks (who
+    cannot be told without an exchange) learn of it at the next synchronisation point, where every rank returns it --
+    the chunk keeps its place in the layout meanwhile, as on the peers."""
+    f = fl.open(str(tmp_path / "r.gsd"), "w", application="app", schema="hoomd", schema_version=[1, 4])
+    f.set_partition([7, 7])
+    small_frame(f, 0)
+    with pytest.raises(RuntimeError, match="Invalid pgsd argument"):
+        f.write_chunk("particles/position", np.zeros((5, 3), np.float32), offset="auto")
+    size_after = f.file_size
+    with pytest.raises(RuntimeError, match="Invalid pgsd argument"):
+        f.end_frame()                                   # this rank is reminded when it seals the frame ...
+    with pytest.raises(RuntimeError, match="Invalid pgsd argument"):
+        f.flush()                                       # ... and the synchronisation point tells everybody (once)
+    f.set_partition(None)
+    f.close()
+    g = fl.open(str(tmp_path / "r.gsd"), "r")
+    assert g.nframes == 1 and g.read_chunk(0, "particles/position").shape == (14, 3)      # the place is there
+    assert size_after >= 5376 + 14 * 12
+    g.close()

@@ -153,7 +153,7 @@ def test_product_equals_oracle_on_random_scenarios(seed, P, tmp_path):
     assert p_log == o_log
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("seed,P", [(seed, P) for seed in range(200, 216) for P in (1, 2, 3)])
 def test_product_with_batched_frame_exchange_equals_oracle_on_random_scenarios(seed, P, mode, tmp_path):
     """The same random call sequences with pgsd_set_frame_exchange(1) on every handle: replicated small
@@ -165,7 +165,8 @@ def test_product_with_batched_frame_exchange_equals_oracle_on_random_scenarios(s
     o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "product.gsd")
     o_log = S.run_oracle(str(scn), o_path, P)
     assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
-    # mode 2: per-particle host chunks are deferred to the frame's exchange as well (pgsd_set_deferred_rows)
+    # mode 2: per-particle host chunks are deferred to the frame's exchange as well (pgsd_set_deferred_rows);
+    # mode 3: declared partition (pgsd_set_partition): no exchange wherever the declaration covers a chunk
     p_log = product.run_driver(product.batched_script(str(scn), str(tmp_path / "batched.scn"), mode), p_path, P)
     with open(o_path, "rb") as a, open(p_path, "rb") as b:
         assert a.read() == b.read()

@@ -141,7 +141,11 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False, batched=Fa
         n = counts[rank]
         row0 = int(sum(counts[:rank]))
         f = fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4])
-        f.frame_exchange = batched      # batched: ONE exchange per frame, the partition derived from it
+        declared = batched == "declared"
+        f.frame_exchange = bool(batched) and not declared      # batched: ONE exchange per frame, the partition derived from it
+        if declared:                    # pgsd_set_partition: the ranks' row counts are declared, NO exchange per frame
+            f.set_partition(counts)
+        c_open = f.collective_count
         for frame in range(2):
             pos = S.gen_data(9, seed + frame, row0, n, 4)
             tid = S.gen_data(3, seed + frame, row0, n, 1)
@@ -152,7 +156,9 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False, batched=Fa
                             ('particles/typeid', fl.DeviceField.from_tensor(dtid, out_dtype=np.uint32))],
                            offset="auto" if batched else np.array(counts), rank=rank)
             f.end_frame(wait=not async_seal)
-        if batched:
+        if declared:
+            assert f.collective_count == c_open        # two frames, not one collective
+        elif batched:
             assert f.collective_count <= 2 + 2 + 1     # create/open, one per frame, the barrier of close (counted after)
         f.close()
         _lib.lib.pgsd_comm_finalize()
@@ -163,7 +169,7 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False, batched=Fa
         raise
 
 
-@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("batched", [False, True, "declared"])
 @pytest.mark.parametrize("async_seal", [False, True])
 @pytest.mark.parametrize("counts", [[600, 401], [0, 333, 1]])
 def test_multi_rank_device_write_matches_oracle(counts, async_seal, batched, tmp_path):
@@ -196,7 +202,7 @@ def test_multi_rank_device_write_matches_oracle(counts, async_seal, batched, tmp
         assert a.read() == b.read()
 
 
-@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("batched", [False, True, "declared"])
 def test_five_ranks_share_the_gpu(batched, tmp_path):
     """as many ranks as the box lets use the card next to the test process itself (6 processes in all): uneven
     partition with an empty and a one-row rank"""

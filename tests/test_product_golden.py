@@ -26,13 +26,15 @@ def test_product_matches_reference_file(name, P, tmp_gsd):
     assert log == S.read_log(golden[:-4] + ".log")
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("name,P", S.golden_cases())
 def test_product_with_batched_frame_exchange_matches_reference_file(name, P, mode, tmp_gsd, tmp_path):
     """pgsd_set_frame_exchange(1): small replicated chunks are queued and ONE allgather per frame places them
     (the device chunks of the GPU tests likewise) -- the file and the state trace must not change by a byte.
     mode 2 adds pgsd_set_deferred_rows(1): per-particle host chunks wait in the queue too (their rows borrowed
-    until the exchange), so every frame of every golden is placed by ONE exchange."""
+    until the exchange), so every frame of every golden is placed by ONE exchange.  mode 3: declared partition
+    (pgsd_set_partition before every chunk, per-particle chunks written with PGSD_PARTITION_AUTO): chunks are placed
+    with NO exchange at all wherever the declaration can express their sizes."""
     scn = product.batched_script(S.scenario_path(name), str(tmp_path / "batched.scn"), mode)
     golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
     log = product.run_driver(scn, tmp_gsd, P, allow_fail=_fails_on_purpose(golden))

@@ -21,7 +21,7 @@ def asan_driver():
     return ASAN_DRIVER
 
 
-@pytest.mark.parametrize("batched", [0, 1, 2])
+@pytest.mark.parametrize("batched", [0, 1, 2, 3])
 @pytest.mark.parametrize("name,P", [("sph_full", 4), ("index_expand", 2), ("names_reloc", 5), ("maxbuf", 4),
                                     ("reopen", 2), ("midflush", 3), ("zero_rank", 8), ("alltypes", 1),
                                     ("defaultargs", 3), ("vone_append", 2), ("idxbuf", 3)])
@@ -30,7 +30,8 @@ def test_scenarios_are_sanitizer_clean(asan_driver, name, P, batched, tmp_path):
     script = S.scenario_path(name)
     if batched:     # the queue / frame exchange of pgsd_set_frame_exchange under the sanitizers as well; 2: with
         # pgsd_set_deferred_rows -- the driver frees a chunk's rows at the next end_frame / flush / close / dump,
-        # so a row read after the exchange that should have consumed it is a use-after-free ASan reports
+        # so a row read after the exchange that should have consumed it is a use-after-free ASan reports;
+        # 3: declared partitions (pgsd_set_partition): no exchange where the declaration covers a chunk
         script = product.batched_script(script, str(tmp_path / "batched.scn"), batched)
     shm = "pgsdasan_%s" % uuid.uuid4().hex[:10]
     procs = []

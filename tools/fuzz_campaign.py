@@ -27,7 +27,7 @@ with tempfile.TemporaryDirectory() as tmp:
         for P in (1, 2, 3, 4):
             scn = os.path.join(tmp, "f.scn")
             open(scn, "w").write(F.make_script(seed, P))
-            paths = {k: os.path.join(tmp, k + ".gsd") for k in ("ref", "oracle", "product", "batched", "deferred")}
+            paths = {k: os.path.join(tmp, k + ".gsd") for k in ("ref", "oracle", "product", "batched", "deferred", "declared")}
             for p in paths.values():
                 if os.path.exists(p):
                     os.unlink(p)
@@ -37,6 +37,7 @@ with tempfile.TemporaryDirectory() as tmp:
             p_log = product.run_driver(scn, paths["product"], P)
             b_log = product.run_driver(product.batched_script(scn, os.path.join(tmp, "b.scn")), paths["batched"], P)
             d_log = product.run_driver(product.batched_script(scn, os.path.join(tmp, "d.scn"), 2), paths["deferred"], P)
+            t_log = product.run_driver(product.batched_script(scn, os.path.join(tmp, "t.scn"), 3), paths["declared"], P)
             try:
                 out = subprocess.run([F.MPIEXEC, "-n", str(P), F.REF_DRIVER, scn, paths["ref"]], capture_output=True, timeout=60)
                 finished = out.returncode == 0
@@ -48,7 +49,9 @@ with tempfile.TemporaryDirectory() as tmp:
                 ref_fail += 1
                 same = (open(paths["oracle"], "rb").read() == open(paths["product"], "rb").read()
                         == open(paths["batched"], "rb").read() == open(paths["deferred"], "rb").read()
-                        and p_log == o_log and strip(b_log) == strip(o_log) and strip(d_log) == strip(o_log))
+                        == open(paths["declared"], "rb").read()
+                        and p_log == o_log and strip(b_log) == strip(o_log) and strip(d_log) == strip(o_log)
+                        and strip(t_log) == strip(o_log))
                 if not same:
                     bad.append((seed, P, "oracle/product"))
                     print("MISMATCH (oracle vs product) seed %d P %d" % (seed, P), flush=True)
@@ -56,8 +59,9 @@ with tempfile.TemporaryDirectory() as tmp:
             r_log = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
             data = {k: open(p, "rb").read() for k, p in paths.items()}
             ok = (data["oracle"] == data["ref"] and data["product"] == data["ref"] and data["batched"] == data["ref"]
-                  and data["deferred"] == data["ref"]
-                  and o_log == r_log and p_log == r_log and strip(b_log) == strip(r_log) and strip(d_log) == strip(r_log))
+                  and data["deferred"] == data["ref"] and data["declared"] == data["ref"]
+                  and o_log == r_log and p_log == r_log and strip(b_log) == strip(r_log) and strip(d_log) == strip(r_log)
+                  and strip(t_log) == strip(r_log))
             ran += 1
             if not ok:
                 bad.append((seed, P))
@@ -65,5 +69,5 @@ with tempfile.TemporaryDirectory() as tmp:
         if (seed - first) % 25 == 24:
             print("seeds %d..%d: %d three-way cases identical, %d mismatches, %d the reference did not finish"
                   % (first, seed, ran - len(bad), len(bad), ref_fail), flush=True)
-print("TOTAL: %d cases (seeds %d..%d x 1-4 ranks): reference == oracle == product == product(batched) == product(batched, deferred rows) in %d, mismatches %s, "
+print("TOTAL: %d cases (seeds %d..%d x 1-4 ranks): reference == oracle == product == product(batched) == product(batched, deferred rows) == product(declared partitions) in %d, mismatches %s, "
       "reference did not finish %d (oracle == product there)" % (ran, first, first + count - 1, ran - len(bad), bad, ref_fail))
