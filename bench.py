@@ -297,6 +297,10 @@ def main():
                     help="roofline.traffic (HBM bytes of one pack launch from the PMC counters): live = two child runs "
                          "of this script under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; N=1 "
                          "only), falling back to file = profiles/pack_traffic.json when that is not possible")
+    ap.add_argument("--declared-partition", action="store_true",
+                    help="pgsd_set_partition instead of the per-frame allgather: every rank's row count is declared once "
+                         "(weak scaling: the same on all ranks), frames then cost NO collective (collectives_per_frame 0). "
+                         "The default keeps the north_star's shape: one allgather of chunk sizes per frame")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -431,7 +435,10 @@ def main():
     # single allgather (one ncclAllGather over xGMI on the RCCL back end, in flight while the kernel runs)
     # carries every rank's chunk sizes, from which each rank derives N_global, its first row and all file
     # offsets (offset="auto": the MPI_Allgather of benchmark-write.cc:39-45 is inside that exchange).
-    f.frame_exchange = True
+    if args.declared_partition:
+        f.set_partition([N] * world)
+    else:
+        f.frame_exchange = True
 
     def step(i):
         f.write_chunk("configuration/step", np.array([i], dtype=np.uint64), write_all=False)
@@ -554,6 +561,7 @@ def main():
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
         "comm_backend": comm_backend,
+        "placement": "declared partition (pgsd_set_partition)" if args.declared_partition else "one allgather of chunk sizes per frame",
         "collectives_per_frame": collectives_per_frame,
         "exchange_us": exchange_us,
         "exchange_probe": exchange_probe,

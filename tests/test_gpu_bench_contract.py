@@ -90,3 +90,14 @@ def test_single_rank_line_carries_the_exchange_probe():
     if pr is None:
         pytest.skip("no RCCL on this box")
     assert pr["bytes"] == 512 and 0 < pr["min_us"] <= pr["median_us"] <= pr["p99_us"]
+
+
+def test_declared_partition_run_costs_no_collective_per_frame():
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+            "--particles", "200000", "--traffic", "off", "--no-cpu-baseline", "--rehearse-shared-gpu", "--declared-partition"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 2 and d["collectives_per_frame"] == 0.0 and "declared" in d["placement"]
+    assert d["exchange_us"]["per_rank_count"] == 0 and d["value"] > 0
