@@ -9,7 +9,9 @@
 //   pgsd_end_frame       -> ONE allgather of the ranks' chunk sizes (it also yields the row partition, the
 //                           MPI_Allgather of benchmark-write.cc:39-45), placement, copies, writes, index
 // (pgsd_set_frame_exchange; pass "perchunk" as 4th argument for one exchange per chunk and the caller-side
-// pgsd_partition_rows instead) and prints MB/s the way the reference's benchmark does, as one JSON line on rank 0.
+// pgsd_partition_rows instead; "declared": the row counts exchanged ONCE before the first frame are declared with
+// pgsd_set_partition and the frames then cost no collective at all) and prints MB/s the way the reference's
+// benchmark does, as one JSON line on rank 0.
 // With "rccl" as 5th argument the ranks bootstrap the library's RCCL communicator themselves -- rank 0's
 // ncclUniqueId travels over the shm communicator they met on -- and every exchange of the run is an
 // ncclAllGather over xGMI: the path a C++ caller (HOOMD-SPH's dump writer) takes without MPI or torch.
@@ -17,7 +19,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
 // With "keep" as 6th argument the file is left behind (benchmark_read.hip reads it back and checks the values).
 //
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk] [shm|rccl] [keep]
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk|declared] [shm|rccl] [keep]
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -56,7 +58,8 @@ int main(int argc, char** argv)
     const uint64_t n = argc > 1 ? strtoull(argv[1], NULL, 10) : 10000000ull;
     const int frames = argc > 2 ? atoi(argv[2]) : 10;
     const char* path = argc > 3 ? argv[3] : "/dev/shm/pgsd_benchmark_write.gsd";
-    const bool batched = !(argc > 4 && strcmp(argv[4], "perchunk") == 0);
+    const bool declared = argc > 4 && strcmp(argv[4], "declared") == 0;
+    const bool batched = !declared && !(argc > 4 && strcmp(argv[4], "perchunk") == 0);
     const bool keep = argc > 6 && strcmp(argv[6], "keep") == 0;
     CHECK(pgsd_comm_init_from_env());
     const int rank = pgsd_comm_rank(), P = pgsd_comm_size();
@@ -107,12 +110,14 @@ int main(int argc, char** argv)
     req[2].src = {pos, NULL, PGSD_TYPE_FLOAT, 4, 3, 1};
 
     CHECK(pgsd_set_frame_exchange(&h, batched ? 1 : 0));
+    if (declared) // the counts pgsd_partition_rows brought above, once: no particle migrates in this harness
+        CHECK(pgsd_set_partition(&h, counts.data(), (uint32_t)P));
     auto frame = [&](uint64_t step) -> int
     {
-        if (!batched)
+        if (!batched && !declared)
             CHECK(pgsd_partition_rows(n, &row0, &n_global, NULL));
         CHECK(pgsd_write_chunk(&h, "configuration/step", PGSD_TYPE_UINT64, 1, 1, 1, 1, 0, 1, false, 0, &step));
-        if (batched)
+        if (batched || declared)
             CHECK(pgsd_write_chunks_device(&h, 3, req, n, PGSD_PARTITION_AUTO, 0));
         else
             CHECK(pgsd_write_chunks_device(&h, 3, req, n, n_global, row0));
@@ -139,7 +144,7 @@ int main(int argc, char** argv)
                "\"collectives_rank0\": %llu, \"comm\": \"%s\"}\n",
                P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
                (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes,
-               batched ? "one per frame" : "one per chunk", collectives, comm_name);
+               declared ? "none (declared partition)" : batched ? "one per frame" : "one per chunk", collectives, comm_name);
         if (!keep)
             unlink(path);
         }

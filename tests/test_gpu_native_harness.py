@@ -85,3 +85,19 @@ def test_read_harness_restores_what_the_write_harness_wrote(tmp_path, writers, r
     assert r["ranks"] == readers and r["frames"] == frames + 1 and r["particles"] == n_global
     assert r["verified"] is True and r["mismatches"] == 0
     assert r["rows_read"] == (frames + 1) * n_global and r["bytes_read"] == (frames + 1) * n_global * 28
+
+
+@pytest.mark.parametrize("writers", [1, 3])
+def test_declared_partition_harness_writes_without_a_collective_per_frame(tmp_path, writers):
+    """`benchmark_write ... declared`: the row counts are exchanged once before the first frame and declared with
+    pgsd_set_partition; the frames then cost the handle NO collective (create/open's two are all it ever issues before
+    close), and the file is the one the read harness verifies value by value."""
+    product.build()
+    path = str(tmp_path / "declared.gsd")
+    per_rank, frames = 70001, 4
+    d = _run_ranks(EXE, [per_rank, frames, path, "declared", "shm", "keep"], writers)
+    assert d["ranks"] == writers and d["exchange"] == "none (declared partition)"
+    assert d["collectives_rank0"] == (2 if writers > 1 else 0), d
+    r = _run_ranks(READ_EXE, [path, "verify"], 2)
+    assert r["verified"] is True and r["mismatches"] == 0 and r["particles"] == per_rank * writers
+    assert r["frames"] == frames + 1
