@@ -302,6 +302,7 @@ class HOOMDTrajectory(object):
             raise ValueError('Append mode not yet supported')
         self._file = file
         self._initial_frame = None
+        self._elision_ref = None       # what append compares against (frame 0; several ranks: its replicated part)
         self._frame0_chunks = None
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
@@ -366,9 +367,16 @@ class HOOMDTrajectory(object):
         frame.validate()
         rank, size = self._comm()
 
-        # the initial frame is the reference for elision
-        if self._initial_frame is None and len(self) > 0:
-            self._read_frame(0)
+        # the initial frame is the reference for elision.  With several ranks only its REPLICATED part is read:
+        # a per-particle array of frame 0 holds all ranks' rows and can never equal this rank's share (round 2 had
+        # every rank read the whole global frame here -- 2.24 GB each at 8 x 10 M particles -- to find that out)
+        if self._elision_ref is None and len(self) > 0:
+            if size == 1:
+                if self._initial_frame is None:
+                    self._read_frame(0)
+                self._elision_ref = self._initial_frame
+            else:
+                self._elision_ref = self._read_frame0_replicated()
         # ... and so is the set of chunks frame 0 holds (hoomd.py:689-691).  Looked up ONCE, by every rank, for
         # every name in the same order -- never from inside a comparison only some ranks make: a lookup flushes
         # whatever is pending, which is collective (a rank whose velocities are all zero would ask alone)
@@ -503,8 +511,8 @@ class HOOMDTrajectory(object):
             return False
         if _is_device(data):
             return True
-        if self._initial_frame is not None:
-            initial_container = getattr(self._initial_frame, path)
+        if self._elision_ref is not None:
+            initial_container = getattr(self._elision_ref, path)
             initial_data = getattr(initial_container, name, None)
             if initial_data is not None and _equal(initial_data, data):
                 logger.debug('skipping data chunk, matches frame 0: ' + path + '/' + name)
@@ -521,6 +529,33 @@ class HOOMDTrajectory(object):
             return False
         return True
 
+    def _read_frame0_replicated(self):
+        """Frame 0's replicated values -- configuration, particle count, types, type shapes, constraints -- for the
+        elision test of `append` on several ranks; per-particle attributes stay None (never compared)."""
+        f = self.file
+        snap = Frame()
+        self._read_scalar_any(0, 'configuration/step', snap.configuration, 'step')
+        self._read_scalar_any(0, 'configuration/dimensions', snap.configuration, 'dimensions')
+        snap.configuration.box = f.read_chunk(0, 'configuration/box') if f.chunk_exists(0, 'configuration/box') \
+            else snap.configuration._default_value['box']
+        for path in ('particles', 'constraints'):
+            container = getattr(snap, path)
+            container.N = int(f.read_chunk(0, path + '/N')[0]) if f.chunk_exists(0, path + '/N') else 0
+        for name in ('types', 'type_shapes'):
+            if f.chunk_exists(0, 'particles/' + name):
+                tmp = f.read_chunk(0, 'particles/' + name)
+                tmp = tmp.view(dtype=numpy.dtype((bytes, tmp.shape[1]))).reshape([tmp.shape[0]])
+                if name == 'types':
+                    snap.particles.types = list(a.decode('UTF-8') for a in tmp)
+                else:
+                    snap.particles.type_shapes = list(json.loads(a.decode('UTF-8')) for a in tmp)
+            else:
+                setattr(snap.particles, name, snap.particles._default_value[name])
+        for name in ('value', 'group'):
+            if f.chunk_exists(0, 'constraints/' + name):
+                setattr(snap.constraints, name, f.read_chunk(0, 'constraints/' + name))
+        return snap
+
     def extend(self, iterable):
         """Append each item of the iterable to the file."""
         for item in iterable:
@@ -530,6 +565,7 @@ class HOOMDTrajectory(object):
         """Close the file."""
         self.file.close()
         del self._initial_frame
+        self._elision_ref = None
 
     def flush(self):
         """Flush all buffered frames to the file."""
