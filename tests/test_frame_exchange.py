@@ -411,3 +411,71 @@ def test_declared_partition_refuses_another_share_at_once_and_reports_it_at_the_
     assert g.nframes == 1 and g.read_chunk(0, "particles/position").shape == (14, 3)      # the place is there
     assert size_after >= 5376 + 14 * 12
     g.close()
+
+
+def _declared_bad_rank(rank, shm, path, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
+        from pgsd import _lib as L
+        import pgsd.fl as F
+        assert L.lib.pgsd_comm_init_shm(shm.encode(), rank, 2) == 0
+        f = F.open(path, "w", application="app", schema="hoomd", schema_version=[1, 4])
+        f.set_partition([5, 5])
+        h = f._h()
+        data = np.arange(15, dtype=np.float32)
+        out = []
+        auto = 2 ** 64 - 1
+        # frame 0: healthy on both ranks, no collective
+        c0 = f.collective_count
+        out.append(L.lib.pgsd_write_chunk(h, b"particles/position", 9, 5, 3, auto, 3, 0, 0, True, 0, data.ctypes.data))
+        out.append(L.lib.pgsd_end_frame(h))
+        out.append(f.collective_count - c0)
+        # frame 1: rank 1 brings a NULL pointer for its rows -- refused there at once; rank 0 cannot know yet
+        ptr = None if rank == 1 else data.ctypes.data
+        out.append(L.lib.pgsd_write_chunk(h, b"particles/position", 9, 5, 3, auto, 3, 0, 0, True, 0, ptr))
+        out.append(L.lib.pgsd_end_frame(h))
+        out.append(L.lib.pgsd_flush(h))             # the synchronisation point: everybody hears of it
+        # frame 2: healthy again -- the refused chunk kept its place, the ranks are still in step
+        out.append(L.lib.pgsd_write_chunk(h, b"particles/position", 9, 5, 3, auto, 3, 0, 0, True, 0, data.ctypes.data))
+        out.append(L.lib.pgsd_end_frame(h))
+        out.append(L.lib.pgsd_flush(h))
+        size = f.file_size
+        f.set_partition(None)
+        f.close()
+        L.lib.pgsd_comm_finalize()
+        q.put((rank, out, size))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), -1))
+        raise
+
+
+def test_declared_partition_a_refusal_on_one_rank_reaches_all_at_the_next_sync_and_the_file_goes_on(tmp_gsd):
+    import multiprocessing as mp
+    import uuid
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = "pgsddecl_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_declared_bad_rank, args=(r, shm, tmp_gsd, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    (r0, out0, size0), (r1, out1, size1) = results
+    assert isinstance(out0, list) and isinstance(out1, list), (out0, out1)
+    assert out0[:3] == [0, 0, 0] and out1[:3] == [0, 0, 0]           # frame 0: fine, and not one collective
+    assert out1[3] == -2 and out0[3] == 0                             # the refusal: on the rank it concerns, at once
+    assert out0[5] == -2 and out1[5] == -2                            # ... on every rank at the synchronisation point
+    assert out0[6:] == [0, 0, 0] and out1[6:] == [0, 0, 0]            # and the file goes on
+    assert size0 == size1 == 5376 + 3 * 10 * 12                       # the layouts stayed in step (three 10-row chunks)
+    g = fl.open(tmp_gsd, "r")
+    assert g.nframes == 3
+    got = g.read_chunk(2, "particles/position")
+    np.testing.assert_array_equal(got, np.tile(np.arange(15, dtype=np.float32).reshape(5, 3), (2, 1)))
+    rank0_rows = g.read_chunk(1, "particles/position")[:5]            # frame 1: rank 0's rows are there, rank 1's a hole
+    np.testing.assert_array_equal(rank0_rows, np.arange(15, dtype=np.float32).reshape(5, 3))
+    g.close()
