@@ -270,17 +270,40 @@ def _equal(a, b):
     a, b = numpy.asarray(a), numpy.asarray(b)
     if a.shape != b.shape:
         return False
-    if a.ndim >= 1 and a.shape[0] > 4096 and not numpy.array_equal(a[:1024], b[:1024]):
+    if a.ndim >= 1 and a.shape[0] > 4096 and not (a[:1024] == b[:1024]).all():
         return False
-    return bool(numpy.array_equal(a, b))
+    return bool((a == b).all())
+
+
+_DEFAULT_AS = {}
 
 
 def _equiv(a, default):
-    """`numpy.array_equiv(a, default)` (default broadcast over the rows), first rows first."""
+    """`numpy.array_equiv(a, default)` (default broadcast over the rows), first rows first.  The schema's defaults
+    are Python lists and ints: compared as they are, a float32 array is promoted to float64 element by element
+    (18 us for 1 024 positions); the default is therefore cast ONCE to the array's type -- when that is exact."""
     a = numpy.asarray(a)
-    if a.ndim >= 1 and a.shape[0] > 4096 and not numpy.array_equiv(a[:1024], default):
+    try:
+        key = (a.dtype, default if not isinstance(default, list) else tuple(default))
+        d = _DEFAULT_AS.get(key)
+    except TypeError:                   # nested / unhashable default: compare the slow way
+        key, d = None, None
+    if d is None:
+        d = numpy.asarray(default)
+        if d.dtype.kind in 'biuf' and a.dtype.kind in 'biuf':
+            with numpy.errstate(all='ignore'):
+                cast = d.astype(a.dtype)
+            if cast.shape == d.shape and (cast == d).all():
+                d = cast
+        if key is not None:
+            _DEFAULT_AS[key] = d
+    if d.ndim and a.shape[a.ndim - d.ndim:] != d.shape:
+        return bool(numpy.array_equiv(a, d))        # not the scalar / one-row defaults of the schema: numpy decides
+    # the first row first: an attribute that is set differs from its default there (and a row-broadcast compare of
+    # a whole (N, 3) array costs 3-4x a dense one)
+    if a.ndim > d.ndim and a.shape[0] > 1 and not (a[0] == d).all():
         return False
-    return bool(numpy.array_equiv(a, default))
+    return bool((a == d).all())
 
 
 def _encode_strings(strings):

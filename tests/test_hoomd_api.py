@@ -280,3 +280,30 @@ def test_state_chunks_round_trip(tmp_gsd):
             assert t[1].state == {}
             np.testing.assert_array_equal(t[2].state['hpmc/sphere/radius'], np.array([0.5, 2.25], dtype=np.float32))
             np.testing.assert_allclose(t[2].state['hpmc/integrate/d'], [0.3])
+
+
+def test_elision_comparisons_agree_with_numpy():
+    """`append` decides what to elide with `_equal` / `_equiv` (typed, cached defaults; first rows first): the
+    decisions must be numpy.array_equal's / numpy.array_equiv's (hoomd.py:673-687) whatever the shapes and types."""
+    import random
+    import numpy
+    from pgsd import hoomd as H
+    rng = numpy.random.default_rng(11)
+    random.seed(11)
+    defaults = [0, 1, -1, 1.5, [0, 0, 0], [1, 0, 0, 0], [0, 1], [1, 1, 1], [0, 0, 0, 0, 0, 0]]
+    for _ in range(4000):
+        shape = tuple(int(x) for x in rng.integers(0, 5, size=rng.integers(0, 3)))
+        dt = random.choice([numpy.float32, numpy.float64, numpy.int32, numpy.uint32, numpy.uint8])
+        a = rng.integers(0, 2, size=shape).astype(dt)
+        b = rng.integers(0, 2, size=shape).astype(dt)
+        d = random.choice(defaults)
+        assert H._equiv(a, d) == bool(numpy.array_equiv(a, d)), (a, d)
+        assert H._equal(a, b) == bool(numpy.array_equal(a, b)), (a, b)
+        assert H._equal(a, a.copy())
+    big = numpy.zeros((10000, 3), dtype=numpy.float32)
+    assert H._equiv(big, [0, 0, 0]) and H._equal(big, big.copy())
+    big[9999, 2] = 1
+    assert not H._equiv(big, [0, 0, 0]) and not H._equal(big, numpy.zeros_like(big))
+    assert not H._equal(big, big[:-1])
+    nan = numpy.array([numpy.nan], dtype=numpy.float32)
+    assert not H._equal(nan, nan) and not H._equiv(nan, numpy.nan)      # array_equal's NaN semantics are kept
