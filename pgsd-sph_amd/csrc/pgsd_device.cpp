@@ -33,6 +33,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <cerrno>
 #include <mutex>
@@ -242,6 +243,8 @@ class DevicePipeline
         m_direct_max = (size_t)2048 << 10;
         if (const char* v = getenv("PGSD_DIRECT_MAX_KIB"))
             m_direct_max = (size_t)(atoll(v) > 0 ? atoll(v) : 0) << 10;
+        if (const char* v = getenv("PGSD_DIRECT_COALESCE")) // 0: one pwrite per chunk (for A/B measurements)
+            m_coalesce = atoi(v) != 0;
         ParkedResources adopted;
         bool have_parked = false;
             {
@@ -1016,14 +1019,32 @@ class DevicePipeline
         long long file_offset;
         };
 
-    // pwrite the packed bytes of direct chunks (their launch is known to have finished)
+    // pwrite the packed bytes of direct chunks (their launch is known to have finished).  Chunks that follow each
+    // other in the file -- a rank's share of a one-rank file, or of any chunk list whose rows this rank owns
+    // alone -- go out in ONE pwritev: a small frame with the full schema is 14-20 chunks of a few KiB, and the
+    // system call was most of what each of them cost.
     void write_direct(const std::vector<DirectWrite>& list)
         {
-        for (const DirectWrite& d : list)
+        std::vector<struct iovec> iov;
+        for (size_t i = 0; i < list.size();)
             {
-            TraceRange tr("pgsd:pwrite_direct file_off=%llu bytes=%llu", (unsigned long long)d.file_offset, d.bytes);
+            size_t j = i;
+            size_t bytes = 0;
+            iov.clear();
+            while (j < list.size() && list[j].file_offset == list[i].file_offset + (long long)bytes
+                   && (j == i || m_coalesce))
+                {
+                if (list[j].bytes > 0)
+                    iov.push_back({(void*)list[j].host, list[j].bytes});
+                bytes += list[j].bytes;
+                j++;
+                }
+            TraceRange tr("pgsd:pwrite_direct file_off=%llu bytes=%llu", (unsigned long long)list[i].file_offset, bytes);
             auto t0 = std::chrono::steady_clock::now();
-            int w = pwrite_locked(m_fd, d.host, d.bytes, d.file_offset, m_shared);
+            int w = iov.empty() ? 0
+                    : iov.size() == 1
+                        ? pwrite_locked(m_fd, iov[0].iov_base, iov[0].iov_len, list[i].file_offset, m_shared)
+                        : pwritev_locked(m_fd, iov.data(), (int)iov.size(), list[i].file_offset, m_shared);
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (w != 0)
                 {
@@ -1031,8 +1052,9 @@ class DevicePipeline
                 return;
                 }
             std::lock_guard<std::mutex> g(m_mutex);
-            m_stats.written_bytes += d.bytes;
+            m_stats.written_bytes += bytes;
             m_stats.write_ms += ms;
+            i = j;
             }
         }
 
@@ -1422,6 +1444,7 @@ class DevicePipeline
     char* m_ddev = nullptr;
     size_t m_dcap = 0, m_dused = 0, m_direct_max = 0;
     bool m_direct_failed = false;
+    bool m_coalesce = true;                // neighbours in the file leave in one pwritev (write_direct)
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
     WriterPool* m_pool = nullptr;
     ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <sched.h>
+#include <sys/uio.h>
 #include <functional>
 #include <memory>
 #include <string>
@@ -86,6 +87,7 @@ int writer_pool_pwrite_sync(WriterPool*, int fd, const void* buf, size_t bytes, 
                             bool shared_file = false);
 // pwrite_full under an advisory flock when several processes write the same file
 int pwrite_locked(int fd, const void* buf, size_t bytes, long long offset, bool shared_file);
+int pwritev_locked(int fd, struct iovec* iov, int n, long long offset, bool shared_file); // one contiguous file range
 // plain full-length pwrite / pread loops (0 / -errno; pread leaves a short tail untouched)
 int pwrite_full(int fd, const void* buf, size_t bytes, long long offset);
 void pread_some(int fd, void* buf, size_t bytes, long long offset);

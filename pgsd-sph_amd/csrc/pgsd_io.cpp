@@ -15,6 +15,7 @@
 #include <string>
 #include <cstdlib>
 #include <sys/file.h>
+#include <sys/uio.h>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -64,6 +65,61 @@ int pwrite_locked(int fd, const void* buf, size_t bytes, long long offset, bool 
             return pwrite_full(fd, buf, bytes, offset); // no lock support: write anyway
     int rc = pwrite_full(fd, buf, bytes, offset);
     flock(fd, LOCK_UN);
+    return rc;
+    }
+
+// Several buffers, one contiguous file range, one system call (the chunks of a small frame follow each other in
+// the file but not necessarily in memory).  `iov` is consumed.
+int pwritev_locked(int fd, struct iovec* iov, int n, long long offset, bool shared_file)
+    {
+    if (g_write_lock < 0)
+        {
+        const char* e = getenv("PGSD_WRITE_LOCK");
+        g_write_lock = (e && atoi(e) == 0) ? 0 : 1;
+        }
+    bool locked = false;
+    if (shared_file && g_write_lock)
+        {
+        locked = true;
+        while (flock(fd, LOCK_EX) != 0)
+            if (errno != EINTR)
+                {
+                locked = false; // no lock support: write anyway
+                break;
+                }
+        }
+    int rc = 0;
+    while (n > 0)
+        {
+        ssize_t w = pwritev(fd, iov, n > 1024 ? 1024 : n, (off_t)offset);
+        if (w < 0)
+            {
+            if (errno == EINTR)
+                continue;
+            rc = -errno;
+            break;
+            }
+        offset += w;
+        size_t left = (size_t)w;
+        while (n > 0 && left >= iov->iov_len)
+            {
+            left -= iov->iov_len;
+            iov++;
+            n--;
+            }
+        if (n > 0 && left > 0)
+            {
+            iov->iov_base = (char*)iov->iov_base + left;
+            iov->iov_len -= left;
+            }
+        else if (n > 0 && w == 0 && iov->iov_len > 0)
+            {
+            rc = -EIO; // no progress on a non-empty buffer
+            break;
+            }
+        }
+    if (locked)
+        flock(fd, LOCK_UN);
     return rc;
     }
 

@@ -1,6 +1,7 @@
 """Host file layer under AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available on the
 pool): the scenario driver built with -fsanitize=address,undefined replays golden scenarios with one
 process per rank; no report may appear and the files must still match the goldens."""
+import fcntl
 import os
 import subprocess
 import uuid
@@ -13,9 +14,17 @@ import scenario as S
 ASAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_asan")
 
 
+def _make(target):
+    """`make <target>` under a file lock: pytest-xdist workers would otherwise relink a binary another one is running."""
+    os.makedirs(os.path.join(product.CSRC, "build"), exist_ok=True)
+    with open(os.path.join(product.CSRC, "build", ".sanitizer_build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return subprocess.run(["make", "-C", product.CSRC, target], capture_output=True)
+
+
 @pytest.fixture(scope="module")
 def asan_driver():
-    r = subprocess.run(["make", "-C", product.CSRC, "asan"], capture_output=True)
+    r = _make("asan")
     if r.returncode != 0 or not os.path.exists(ASAN_DRIVER):
         pytest.skip("sanitizer build not available: " + r.stderr.decode()[-300:])
     return ASAN_DRIVER
@@ -71,7 +80,7 @@ close
 def test_writer_pool_and_read_threads_are_race_free(tmp_path):
     """ThreadSanitizer over the threads the host layer starts inside one process: 84 MB chunks are split over the
     writer pool on the way out and over the host read threads on the way in.  The file must equal the oracle's."""
-    r = subprocess.run(["make", "-C", product.CSRC, "tsan"], capture_output=True)
+    r = _make("tsan")
     if r.returncode != 0 or not os.path.exists(TSAN_DRIVER):
         pytest.skip("sanitizer build not available: " + r.stderr.decode()[-300:])
     scn = tmp_path / "big.scn"
