@@ -353,3 +353,38 @@ def test_stage_now_write_later(batched, tmp_path):
     g = fl.open(mine, 'r')
     assert not g.chunk_exists(0, "particles/never_written") and g.nframes == 4
     g.close()
+
+
+@pytest.mark.parametrize("coalesce", ["1", "0"])
+def test_direct_chunks_in_one_pwritev_or_one_by_one_are_the_same_file(tmp_path, monkeypatch, coalesce):
+    """Small-frame (direct) path: neighbouring chunks leave in one pwritev (default) or one pwrite each
+    (PGSD_DIRECT_COALESCE=0); odd sizes so that the pieces are not contiguous in the pinned arena,
+    several frames, sealed synchronously and asynchronously.  Reference: the same chunks from host arrays."""
+    import pgsd.fl as fl
+    monkeypatch.setenv("PGSD_DIRECT_COALESCE", coalesce)
+    monkeypatch.setenv("PGSD_NO_PARKING", "1")           # a parked pipeline keeps the setting it was made with
+    rng = np.random.default_rng(5)
+    N = 1237
+    arrays = [rng.standard_normal((N, 4)).astype(np.float32) for _ in range(9)]
+    ids = rng.integers(0, 1 << 30, size=N).astype(np.uint32)
+    a, b = str(tmp_path / "dev.gsd"), str(tmp_path / "host.gsd")
+    with fl.open(a, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        f.frame_exchange = True
+        for frame in range(4):
+            fields = [('particles/a%d' % k, fl.DeviceField.from_tensor(dev(x), columns=(0, 1 + k % 3)))
+                      for k, x in enumerate(arrays)]
+            fields.insert(4, ('particles/typeid', fl.DeviceField.from_tensor(dev(ids.view(np.int32)), out_dtype=np.uint32)))
+            f.write_chunk('configuration/step', np.array([frame], dtype=np.uint64), write_all=False)
+            f.write_chunks(fields, offset='auto')
+            f.end_frame(wait=(frame % 2 == 0))
+        f.frame_sync()
+    with fl.open(b, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        for frame in range(4):
+            f.write_chunk('configuration/step', np.array([frame], dtype=np.uint64), write_all=False)
+            for k, x in enumerate(arrays):
+                if k == 4:
+                    f.write_chunk('particles/typeid', ids)
+                f.write_chunk('particles/a%d' % k, np.ascontiguousarray(x[:, :1 + k % 3]))
+            f.end_frame()
+    with open(a, 'rb') as fa, open(b, 'rb') as fb:
+        assert fa.read() == fb.read()
