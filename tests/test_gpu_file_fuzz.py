@@ -2,8 +2,9 @@
 both sides of the direct-path threshold (set to 64 KiB here, so frames of a few thousand rows already mix the two
 roads: packed straight into pinned host memory and written by the sealing thread / staged in HBM, copied, written by
 the pipeline), random field sets (float4 and double4 sources, the type id as bits of position.w, scalar and int3
-arrays), replicated host chunks in between, the frame exchange batched or not, frames sealed synchronously or
-asynchronously, host per-particle arrays with and without deferred rows.  Seeds are fixed."""
+arrays), replicated host chunks in between, the frame exchange batched or not or a declared partition
+(pgsd_set_partition, offset='auto'), frames sealed synchronously or asynchronously, host per-particle arrays with and
+without deferred rows, neighbouring direct chunks in one pwritev or one pwrite each.  Seeds are fixed."""
 import os
 
 import numpy as np
@@ -31,6 +32,9 @@ def test_random_frames_match_the_oracle_file(seed, tmp_path, monkeypatch):
     mine, ref = str(tmp_path / "mine.gsd"), str(tmp_path / "ref.gsd")
     batched = bool(rng.random() < 0.6)
     deferred = batched and bool(rng.random() < 0.5)
+    declared = not batched and bool(rng.random() < 0.5)
+    if rng.random() < 0.3:
+        monkeypatch.setenv("PGSD_DIRECT_COALESCE", "0")
     f = fl.open(mine, "w", application="app", schema="hoomd", schema_version=[1, 4])
     if rng.random() < 0.3:
         f.configure_device(slab_bytes=int(rng.choice([4096, 65536, 1 << 20])), n_slabs=int(rng.integers(1, 4)))
@@ -51,6 +55,9 @@ def test_random_frames_match_the_oracle_file(seed, tmp_path, monkeypatch):
         dpos, dvel, dimg, ddens, dtid = dev(pos), dev(vel), dev(img), dev(dens), dev(tid.view(np.int32))
         keep += [dpos, dvel, dimg, ddens, dtid]
         chunks = []
+        rows = "auto" if declared else np.array([N])
+        if declared:
+            f.set_partition([N])
         step = np.array([100 * frame + seed], dtype=np.uint64)
         f.write_chunk("configuration/step", step, write_all=False)
         chunks.append(("configuration/step", 4, 1, False, [step.reshape(1, 1)]))
@@ -70,12 +77,12 @@ def test_random_frames_match_the_oracle_file(seed, tmp_path, monkeypatch):
         cut = int(rng.integers(0, len(picked) + 1))
         for group in (picked[:cut], picked[cut:]):
             if group:
-                f.write_chunks([(name, field) for name, field, _, _, _ in group], offset=np.array([N]))
+                f.write_chunks([(name, field) for name, field, _, _, _ in group], offset=rows)
                 chunks += [(name, t, M, True, [np.ascontiguousarray(exp)]) for name, _, t, M, exp in group]
             if group is picked[:cut] and rng.random() < 0.5:
                 host = G.rand_array(rng, (N, 2), np.float32)
                 keep.append(host)
-                f.write_chunk("particles/host_field", host, offset=np.array([N]))
+                f.write_chunk("particles/host_field", host, offset=rows)
                 chunks.append(("particles/host_field", 9, 2, True, [host]))
         if rng.random() < 0.5:
             box = G.rand_array(rng, (6,), np.float32)
@@ -86,4 +93,4 @@ def test_random_frames_match_the_oracle_file(seed, tmp_path, monkeypatch):
     f.close()
     _oracle_frames(ref, 1, frames)
     with open(mine, "rb") as a, open(ref, "rb") as b:
-        assert a.read() == b.read(), (seed, batched, deferred)
+        assert a.read() == b.read(), (seed, batched, deferred, declared)
