@@ -436,6 +436,24 @@ extern "C"
     int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
                                  uint64_t N_global, uint64_t offset_rows);
 
+    /* Elision for arrays that live in HBM.  pgsd.hoomd does not write a per-particle array that equals frame 0's
+       (reference: hoomd.py:654-694, a numpy comparison of host arrays).  For device arrays the test runs on the
+       GPU, on staged chunks that have not been written yet:
+       pgsd_compare_staged_chunks compares the PACKED bytes of chunks [first, first + count) of a ticket with
+       ref[i] -- device memory holding the same rows of the other frame as the chunk stores them, N * M *
+       sizeof(type) bytes (read with pgsd_read_chunk_device, or kept with pgsd_copy_staged_chunks) -- and sets
+       equal[i] = 1 when every byte matches, 0 when not or when ref[i] is NULL (a rank without rows: 1).  One
+       kernel launch behind the pack, one stream wait; local, no collective: the caller agrees the outcome over
+       the ranks like any other write / skip decision and then writes (pgsd_write_staged_chunks) or does not
+       (unwritten chunks are dropped by pgsd_end_frame).  Byte equality: NaNs with equal bits are equal, -0.0 and
+       0.0 are not -- eliding is always safe, a reader gets the same bits back from frame 0.
+       pgsd_copy_staged_chunks copies the packed bytes into caller-owned device memory dst[i] (NULL: skipped),
+       asynchronously behind the pack: complete after pgsd_device_wait_packed, a comparison or pgsd_end_frame. */
+    int pgsd_compare_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                   const void* const* ref, uint8_t* equal);
+    int pgsd_copy_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                void* const* dst);
+
     /* Seal the frame like pgsd_end_frame, but do not wait for its device chunks: the frame
        counter advances and names / small-chunk buffers / index entries are committed now, while
        the device->host copies and the pwrite()s of the frame keep running behind the caller.

@@ -358,6 +358,10 @@ class DevicePipeline
             writer_pool_destroy(m_pool); // joins the writers
         (void)hipSetDevice(m_cfg.device);
         release_events();
+        if (m_cmp_host)
+            (void)hipHostFree(m_cmp_host);
+        if (m_cmp_dev)
+            (void)hipFree(m_cmp_dev);
         if (park())
             return;
         for (hipEvent_t e : m_pool_plain)
@@ -613,6 +617,106 @@ class DevicePipeline
         for (size_t i = 0; i < chunks.size() && rc == PGSD_SUCCESS; i++)
             rc = commit(ticket, i, chunks[i].host_dst ? -1 : chunks[i].file_offset, chunks[i].host_dst);
         return rc;
+        }
+
+    // Packed bytes of staged (not yet committed) chunks against reference bytes in device memory: one kernel behind
+    // the pack on the pack stream, one stream wait, the answers in pinned words the kernel wrote across PCIe.
+    int compare(int ticket, size_t first, size_t count, const void* const* ref, uint8_t* equal)
+        {
+        if (!m_ok)
+            return PGSD_ERROR_NO_DEVICE;
+        if (failed())
+            return PGSD_ERROR_DEVICE;
+        HIP_TRY(hipSetDevice(m_cfg.device));
+        std::vector<CompareJob> jobs;
+        std::vector<size_t> who;
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            auto it = m_staged.find(ticket);
+            if (it == m_staged.end() || first + count > it->second.chunks.size())
+                return PGSD_ERROR_INVALID_ARGUMENT;
+            for (size_t i = 0; i < count; i++)
+                {
+                const DeviceChunk& c = it->second.chunks[first + i];
+                const uint64_t bytes = c.N * c.job.M * sizeof_type(c.job.dst_type);
+                equal[i] = ref[i] != nullptr && bytes == 0 ? 1 : 0; // no rows here: nothing that could differ
+                if (ref[i] != nullptr && bytes > 0)
+                    {
+                    jobs.push_back({c.job.dst, ref[i], bytes});
+                    who.push_back(i);
+                    }
+                }
+            }
+        if (jobs.empty())
+            return PGSD_SUCCESS;
+        TraceRange tr("pgsd:compare chunks=%llu", (unsigned long long)jobs.size(), 0ull);
+        if (!m_cmp_host)
+            {
+            void* h = nullptr;
+            void* hd = nullptr;
+            void* d = nullptr;
+            HIP_TRY(hipHostMalloc(&h, CMP_MAX_JOBS * sizeof(uint32_t), hipHostMallocMapped));
+            memset(h, 0, CMP_MAX_JOBS * sizeof(uint32_t));
+            m_cmp_host = (uint32_t*)h;
+            HIP_TRY(hipHostGetDevicePointer(&hd, h, 0));
+            m_cmp_host_dev = (uint32_t*)hd;
+            HIP_TRY(hipMalloc(&d, CMP_MAX_JOBS * sizeof(uint32_t)));
+            m_cmp_dev = (uint32_t*)d;
+            // on the stream the kernels run on: a null-stream memset is not ordered with a non-blocking stream
+            HIP_TRY(hipMemsetAsync(d, 0, CMP_MAX_JOBS * sizeof(uint32_t), m_pack_stream));
+            }
+        for (size_t at = 0; at < jobs.size(); at += CMP_MAX_JOBS)
+            {
+            const uint32_t n = (uint32_t)std::min<size_t>(CMP_MAX_JOBS, jobs.size() - at);
+            // one sequence for the process: a later pipeline may be handed the memory an earlier one marked
+            static std::atomic<uint32_t> next_gen {0};
+            do
+                m_cmp_gen = ++next_gen;
+            while (m_cmp_gen == 0);
+            std::string err;
+            int rc = launch_compare(n, jobs.data() + at, m_cmp_gen, m_cmp_dev, m_cmp_host_dev, m_pack_stream, &err);
+            if (rc != PGSD_SUCCESS)
+                {
+                fail(err);
+                return rc;
+                }
+            hipError_t e = hipStreamSynchronize(m_pack_stream);
+            if (e != hipSuccess)
+                {
+                fail(std::string("hipStreamSynchronize(compare): ") + hipGetErrorString(e));
+                return PGSD_ERROR_DEVICE;
+                }
+            for (uint32_t k = 0; k < n; k++)
+                equal[who[at + k]] = __atomic_load_n(&m_cmp_host[k], __ATOMIC_RELAXED) != m_cmp_gen ? 1 : 0;
+            }
+        return PGSD_SUCCESS;
+        }
+
+    // Packed bytes of staged chunks into caller-owned device memory (frame 0's rows kept for later comparisons):
+    // copies on the pack stream behind the pack, asynchronous.
+    int copy_staged(int ticket, size_t first, size_t count, void* const* dst)
+        {
+        if (!m_ok)
+            return PGSD_ERROR_NO_DEVICE;
+        if (failed())
+            return PGSD_ERROR_DEVICE;
+        HIP_TRY(hipSetDevice(m_cfg.device));
+        std::vector<std::pair<const void*, size_t>> src(count);
+            {
+            std::lock_guard<std::mutex> g(m_mutex);
+            auto it = m_staged.find(ticket);
+            if (it == m_staged.end() || first + count > it->second.chunks.size())
+                return PGSD_ERROR_INVALID_ARGUMENT;
+            for (size_t i = 0; i < count; i++)
+                {
+                const DeviceChunk& c = it->second.chunks[first + i];
+                src[i] = {c.job.dst, (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type))};
+                }
+            }
+        for (size_t i = 0; i < count; i++)
+            if (dst[i] != nullptr && src[i].second > 0)
+                HIP_TRY(hipMemcpyAsync(dst[i], src[i].first, src[i].second, hipMemcpyDefault, m_pack_stream));
+        return PGSD_SUCCESS;
         }
 
     // Asynchronous seal (pgsd_end_frame_async): nobody will call drain() for this frame, so the direct
@@ -1444,6 +1548,10 @@ class DevicePipeline
     char* m_ddev = nullptr;
     size_t m_dcap = 0, m_dused = 0, m_direct_max = 0;
     bool m_direct_failed = false;
+    uint32_t* m_cmp_host = nullptr;        // compare(): answers, pinned; its device alias; the early-exit words in HBM
+    uint32_t* m_cmp_host_dev = nullptr;
+    uint32_t* m_cmp_dev = nullptr;
+    uint32_t m_cmp_gen = 0;
     bool m_coalesce = true;                // neighbours in the file leave in one pwritev (write_direct)
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
     WriterPool* m_pool = nullptr;
@@ -1503,6 +1611,24 @@ int device_pipeline_commit(DevicePipeline* p, int ticket, size_t index, long lon
                            std::string* err)
     {
     int rc = p->commit(ticket, index, file_offset, host_dst);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_compare(DevicePipeline* p, int ticket, size_t first, size_t count, const void* const* ref,
+                            uint8_t* equal, std::string* err)
+    {
+    int rc = p->compare(ticket, first, count, ref, equal);
+    if (rc != PGSD_SUCCESS && err)
+        *err = p->error();
+    return rc;
+    }
+
+int device_pipeline_copy_staged(DevicePipeline* p, int ticket, size_t first, size_t count, void* const* dst,
+                                std::string* err)
+    {
+    int rc = p->copy_staged(ticket, first, count, dst);
     if (rc != PGSD_SUCCESS && err)
         *err = p->error();
     return rc;

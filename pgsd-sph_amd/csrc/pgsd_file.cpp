@@ -2625,6 +2625,73 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
+// staged chunks [first, first + count) of a ticket that have not been written yet
+static int staged_range(Impl* s, uint64_t ticket, uint32_t first, uint32_t count, EarlyStage** out)
+    {
+    if (!s || count == 0)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    auto it = s->early.find(ticket);
+    if (it == s->early.end() || (uint64_t)first + count > it->second.claimed.size())
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    for (uint32_t i = first; i < first + count; i++)
+        if (it->second.claimed[i])
+            return PGSD_ERROR_INVALID_ARGUMENT;
+    *out = &it->second;
+    return PGSD_SUCCESS;
+    }
+
+extern "C" int pgsd_compare_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                          const void* const* ref, uint8_t* equal)
+    try
+    {
+    Impl* s = impl_of(handle);
+    EarlyStage* e = nullptr;
+    if (!ref || !equal)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = staged_range(s, ticket, first, count, &e);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    memset(equal, 0, count);
+    if (e->local_rc != PGSD_SUCCESS || e->ticket < 0)
+        return e->local_rc != PGSD_SUCCESS ? e->local_rc : PGSD_ERROR_DEVICE; // the staging failed: nothing to compare
+    std::string err;
+    rc = device_pipeline_compare(s->dev, e->ticket, first, count, ref, equal, &err);
+    if (rc != PGSD_SUCCESS)
+        {
+        set_last_error(err);
+        memset(equal, 0, count);
+        }
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_copy_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
+                                       void* const* dst)
+    try
+    {
+    Impl* s = impl_of(handle);
+    EarlyStage* e = nullptr;
+    if (!dst)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int rc = staged_range(s, ticket, first, count, &e);
+    if (rc != PGSD_SUCCESS)
+        return rc;
+    if (e->local_rc != PGSD_SUCCESS || e->ticket < 0)
+        return e->local_rc != PGSD_SUCCESS ? e->local_rc : PGSD_ERROR_DEVICE;
+    std::string err;
+    rc = device_pipeline_copy_staged(s->dev, e->ticket, first, count, dst, &err);
+    if (rc != PGSD_SUCCESS)
+        set_last_error(err);
+    return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
 extern "C" int pgsd_read_chunk_device(struct pgsd_handle* handle, const struct pgsd_index_entry* chunk, uint64_t N,
                                       uint64_t row_offset, const struct pgsd_field_dst* dst)
     try

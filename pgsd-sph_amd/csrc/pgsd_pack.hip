@@ -1130,6 +1130,113 @@ __global__ __launch_bounds__(256) void fill_cols_kernel(const FillArgs a)
         }
     }
 
+// ------------------------------------------------------------------ packed chunk == reference bytes ?
+// pgsd.hoomd elides a per-particle array that equals frame 0's (hoomd.py:654-694).  For arrays that live in HBM the
+// test runs here: the chunk is packed as usual, then its packed bytes are compared with the reference rows (also in
+// device memory) -- 16 bytes per lane and load, four loads of each side in flight, grid-stride.  Bandwidth-bound when the
+// arrays are equal (2 x chunk bytes read, nothing written).  Arrays that differ differ early, so a PROBE launch -- four
+// workgroups per job over its first 64 KiB -- runs first: the full launch's workgroups of a job the probe marked leave
+// at once (had they all found the difference themselves, thousands of waves would each have sent their mark across
+// PCIe: 237 us for two moving arrays of 10 M rows against 129 us for six equal ones).  A difference further in is still
+// found by the full launch; the first workgroup to see it marks the job and the others stop at their next stride.
+// The flag words are never cleared: a launch marks with its own generation number.
+__global__ __launch_bounds__(256) void compare_bytes_kernel(const CompareArgs args)
+    {
+    CompareJob jb = args.j[blockIdx.y];
+    uint32_t* df = args.dflags + blockIdx.y;
+    if (args.limit != 0 && jb.bytes > args.limit)
+        jb.bytes = args.limit;
+    if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == args.gen)
+        return; // marked by the probe (or by a quicker workgroup)
+    bool diff = false;
+    const char* pa = (const char*)jb.a;
+    const char* pb = (const char*)jb.b;
+    uint64_t done = 0; // bytes covered by the vector loop
+    if ((((uintptr_t)pa | (uintptr_t)pb) & 15) == 0)
+        {
+        const u32x4* a = (const u32x4*)pa;
+        const u32x4* b = (const u32x4*)pb;
+        const uint64_t n16 = jb.bytes >> 4;
+        done = n16 << 4;
+        const uint64_t per_block = 256 * 4;
+        for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n16; base += (uint64_t)gridDim.x * per_block)
+            {
+            if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == args.gen)
+                break;
+            u32x4 x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                {
+                const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+                x[k] = (u32x4)(0u);
+                y[k] = (u32x4)(0u);
+                if (i < n16)
+                    {
+                    x[k] = __builtin_nontemporal_load(a + i);
+                    y[k] = __builtin_nontemporal_load(b + i);
+                    }
+                }
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                acc |= (x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w);
+            if (acc != 0)
+                {
+                diff = true;
+                break;
+                }
+            }
+        }
+    // what the vector loop left: the last bytes, or everything when a side is not 16-byte aligned
+    for (uint64_t i = done + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < jb.bytes && !diff; i += (uint64_t)gridDim.x * 256)
+        diff = pa[i] != pb[i];
+    const uint64_t who = __ballot(diff);
+    if (who != 0 && (uint32_t)(__ffsll((unsigned long long)who) - 1) == (threadIdx.x & 63u))
+        {
+        __hip_atomic_store(df, args.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(args.hflags + blockIdx.y, args.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+
+int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32_t* dflags, uint32_t* hflags,
+                   hipStream_t stream, std::string* err)
+    {
+    if (n_jobs == 0)
+        return PGSD_SUCCESS;
+    if (n_jobs > CMP_MAX_JOBS || !jobs || !dflags || !hflags)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    CompareArgs args;
+    memset(&args, 0, sizeof(args));
+    args.dflags = dflags;
+    args.hflags = hflags;
+    args.gen = gen;
+    args.n_jobs = n_jobs;
+    uint64_t most = 0;
+    for (uint32_t i = 0; i < n_jobs; i++)
+        {
+        args.j[i] = jobs[i];
+        most = std::max<uint64_t>(most, jobs[i].bytes);
+        }
+    // one workgroup per 16 KiB of the longest job, at most eight per CU of the part (2048): grid-stride beyond
+    uint64_t blocks = (most + 16383) / 16384;
+    blocks = std::min<uint64_t>(std::max<uint64_t>(blocks, 1), 2048);
+    if (most > 65536)
+        {
+        args.limit = 65536;
+        hipLaunchKernelGGL(compare_bytes_kernel, dim3(4, n_jobs), dim3(256), 0, stream, args); // 16 KiB per workgroup
+        args.limit = 0;
+        }
+    hipLaunchKernelGGL(compare_bytes_kernel, dim3((unsigned)blocks, n_jobs), dim3(256), 0, stream, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        {
+        if (err)
+            *err = std::string("compare kernel launch failed: ") + hipGetErrorString(e);
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
+
 // ------------------------------------------------------------------ select (compaction)
 #define SEL_THREADS 256
 #define SEL_PER_THREAD 16

@@ -215,6 +215,33 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
 int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err,
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// ---- byte comparison of packed chunks with reference bytes (pgsd_compare_staged_chunks)
+enum
+    {
+    CMP_MAX_JOBS = 64
+    };
+
+struct CompareJob
+    {
+    const void* a;  // packed chunk (staging: HBM, or the pinned arena of the direct path)
+    const void* b;  // reference bytes in device memory
+    uint64_t bytes;
+    };
+
+struct CompareArgs
+    {
+    uint32_t* dflags; // device memory, one word per job: == gen once a difference was seen (early exit of the other workgroups)
+    uint32_t* hflags; // pinned host memory (device-mapped), one word per job: the answer
+    uint32_t gen;     // this launch's mark: the flag words are never cleared
+    uint32_t n_jobs;
+    uint64_t limit;   // compare at most this many bytes of every job (the probe launch); 0: all
+    CompareJob j[CMP_MAX_JOBS];
+    };
+
+// Enqueue the comparison of `n_jobs` (<= CMP_MAX_JOBS) byte ranges on `stream`; hflags[i] == gen afterwards: they differ.
+int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32_t* dflags, uint32_t* hflags,
+                   hipStream_t stream, std::string* err);
+
 // algorithmic traffic of one job: bytes that must be read (needed columns only, plus the
 // gather index) and chunk bytes written
 uint64_t pack_algorithmic_bytes_in(const pgsd_pack_job& j, uint64_t N);

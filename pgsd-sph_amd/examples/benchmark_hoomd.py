@@ -56,6 +56,9 @@ def run(N, size, path, mode):
 
     def write_all():
         with pgsd.hoomd.open(name=path, mode='w') as hf:
+            # the SAME two tensors are appended every frame: with the GPU-side elision test on (the default) frames
+            # 1.. would equal frame 0 and hold no particle data.  A simulation's arrays move; this measures the write
+            hf.device_elision = False
             for i in range(nframes):
                 if mode == "host":
                     position[0, 0] = i          # every frame differs from frame 0 (benchmark-hoomd.py:27-28):

@@ -750,6 +750,80 @@ cdef class PGSDFile:
             err = errno
         _raise_on_error(retval, self._name, err)
 
+    def compare_staged(self, ticket, first, refs):
+        """Are the packed bytes of staged chunks ``first, first + 1, ...`` of a :meth:`stage_chunks` ticket equal to
+        ``refs[i]`` -- torch GPU tensors holding the same rows of another frame as the chunk stores them
+        (:meth:`read_chunk_device`, :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  One kernel behind the
+        pack, one stream wait (``pgsd_compare_staged_chunks``).  Byte equality.  Returns a list of bool."""
+        self._check_open()
+        cdef Py_ssize_t n = len(refs), i
+        if n == 0:
+            return []
+        cdef uint64_t c_ticket = ticket[0], rows = ticket[1]
+        cdef uint32_t c_first = first, c_count = n
+        cdef const void** ptrs = <const void**>calloc(n, sizeof(void*))
+        cdef uint8_t* eq = <uint8_t*>calloc(n, 1)
+        cdef uintptr_t p
+        cdef int retval, err
+        if ptrs == NULL or eq == NULL:
+            free(ptrs)
+            free(eq)
+            raise MemoryError()
+        try:
+            for i in range(n):
+                r = refs[i]
+                if r is None:
+                    continue
+                if not _is_device_tensor(r) or not r.is_contiguous():
+                    raise ValueError("a reference must be a contiguous torch GPU tensor (or None)")
+                if rows > 0 and (r.numel() * r.element_size()) % rows != 0:
+                    raise ValueError("reference %d does not hold %d rows" % (i, rows))
+                p = r.data_ptr()
+                # an empty tensor has no address: any non-null one says "there is a reference" (no byte is read)
+                ptrs[i] = <const void*>p if p != 0 else <const void*>ptrs
+            with nogil:
+                retval = C.pgsd_compare_staged_chunks(&self._handle, c_ticket, c_first, c_count, ptrs, eq)
+                err = errno
+            _raise_on_error(retval, self._name, err)
+            return [bool(eq[i]) for i in range(n)]
+        finally:
+            free(ptrs)
+            free(eq)
+
+    def copy_staged(self, ticket, first, sizes):
+        """Keep the packed bytes of staged chunks ``first, first + 1, ...`` of a ticket: returns one ``torch.uint8`` GPU
+        tensor of ``sizes[i]`` bytes per chunk (``None`` where ``sizes[i]`` is ``None``), filled asynchronously behind the
+        pack (``pgsd_copy_staged_chunks``) -- references for :meth:`compare_staged` in later frames."""
+        self._check_open()
+        import torch
+        cdef Py_ssize_t n = len(sizes), i
+        if n == 0:
+            return []
+        cdef uint64_t c_ticket = ticket[0]
+        cdef uint32_t c_first = first, c_count = n
+        cdef void** ptrs = <void**>calloc(n, sizeof(void*))
+        cdef uintptr_t p
+        cdef int retval, err
+        if ptrs == NULL:
+            raise MemoryError()
+        out = []
+        try:
+            for i in range(n):
+                if sizes[i] is None:
+                    out.append(None)
+                    continue
+                t = torch.empty(int(sizes[i]), dtype=torch.uint8, device='cuda')
+                out.append(t)
+                p = t.data_ptr()
+                ptrs[i] = <void*>p
+            with nogil:
+                retval = C.pgsd_copy_staged_chunks(&self._handle, c_ticket, c_first, c_count, ptrs)
+                err = errno
+            _raise_on_error(retval, self._name, err)
+            return out
+        finally:
+            free(ptrs)
+
     def wait_packed(self):
         """Block until the pack kernels of the open frame are done (sources may be reused)."""
         cdef int retval

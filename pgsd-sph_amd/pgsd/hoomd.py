@@ -326,7 +326,15 @@ class HOOMDTrajectory(object):
         self._file = file
         self._initial_frame = None
         self._elision_ref = None       # what append compares against (frame 0; several ranks: its replicated part)
+        self._elision_lazy = False     # one rank: per-particle arrays of frame 0 are read when first compared
         self._frame0_chunks = None
+        #: compare GPU-resident per-particle arrays with frame 0 on the GPU and elide the equal ones, as hoomd.py:654-694
+        #: does for host arrays (`append`); False: GPU-resident arrays are always written
+        self.device_elision = True
+        self._dev_ref = {}             # chunk -> GPU tensor: this rank's rows of frame 0 as the chunk stores them
+        self._dev_ref_part = None      # the partition (every rank's row count) those rows belong to
+        self._dev_dynamic = set()      # GPU-resident chunks seen to differ from frame 0: not compared any more
+        self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
             raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
@@ -381,8 +389,12 @@ class HOOMDTrajectory(object):
         * the write/skip decision of every chunk is agreed over the ranks (written if any rank needs
           it; a rank without a value contributes the default for its rows), because a chunk write is
           collective; ``particles/N`` is compared as the global count;
-        * GPU-resident fields are always written (comparing them would cost a device pass and a sync)
-          and all of a frame's consecutive device fields go out in one fused pack launch;
+        * GPU-resident per-particle arrays are compared with frame 0 ON THE GPU (`device_elision`, default on;
+          `_device_elision_votes`): packed by one launch, their packed bytes compared with this rank's rows of frame 0
+          in device memory, the equal ones elided like host arrays -- byte equality, frame 0 itself always written
+          in full (no default-value test), an array that differed once is written from then on without a comparison,
+          a change of the partition ends the comparisons.  ``device_elision = False``: always written, consecutive
+          device fields in one fused pack launch each;
         * upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom) follow the
           SPH set in that order when they are set.
         """
@@ -393,13 +405,15 @@ class HOOMDTrajectory(object):
         # the initial frame is the reference for elision.  With several ranks only its REPLICATED part is read:
         # a per-particle array of frame 0 holds all ranks' rows and can never equal this rank's share (round 2 had
         # every rank read the whole global frame here -- 2.24 GB each at 8 x 10 M particles -- to find that out)
+        # One rank: a per-particle array of frame 0 is read when (and if) a host array is to be compared with it --
+        # reading all of frame 0 here cost the second append of a 10 M-particle trajectory 250 ms, for arrays that live
+        # on the GPU and are compared there (`_device_elision_votes`) never to be looked at.
         if self._elision_ref is None and len(self) > 0:
-            if size == 1:
-                if self._initial_frame is None:
-                    self._read_frame(0)
+            if size == 1 and self._initial_frame is not None:
                 self._elision_ref = self._initial_frame
             else:
                 self._elision_ref = self._read_frame0_replicated()
+                self._elision_lazy = size == 1
         # ... and so is the set of chunks frame 0 holds (hoomd.py:689-691).  Looked up ONCE, by every rank, for
         # every name in the same order -- never from inside a comparison only some ranks make: a lookup flushes
         # whatever is pending, which is collective (a rank whose velocities are all zero would ask alone)
@@ -426,6 +440,7 @@ class HOOMDTrajectory(object):
         # 1. decide locally which chunks to write, then ONE allgather carries every rank's particle count
         #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes
         plan = []
+        dev = []        # GPU-resident per-particle attributes: (index in plan, chunk name, DeviceField), schema order
         for path in ('configuration', 'particles', 'constraints'):
             container = getattr(frame, path)
             names = list(container._default_value)
@@ -436,11 +451,19 @@ class HOOMDTrajectory(object):
                 if (path, name) == ('particles', 'N'):
                     # None = "as in frame 0": no count chunk; decided below from the global count otherwise
                     plan.append((path, name, frame.particles.N is not None))
-                elif values.get(name, values.get('_' + name)) is None:
+                    continue
+                value = values.get(name, values.get('_' + name))
+                if value is None:
                     plan.append((path, name, False))        # most of the schema, most of the time: not set
+                elif path == 'particles' and _is_device(value) and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
+                    dt, _ = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
+                    field = value if isinstance(value, fl.DeviceField) else fl.DeviceField.from_tensor(value, out_dtype=dt)
+                    dev.append((len(plan), path + '/' + name, field))
+                    plan.append((path, name, True))
                 else:
                     plan.append((path, name, self._should_write(path, name, frame, None)))
         n_local = int(frame.particles.N) if frame.particles.N is not None else 0
+        ticket, compared = self._device_elision_votes(frame, dev, plan, rank, size, n_local)
         if frame.part_dist is not None:
             part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
             if part_dist.shape[0] != size:
@@ -459,6 +482,7 @@ class HOOMDTrajectory(object):
         n_global = int(part_dist.sum())
         plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') and w else w)
                 for p, n, w in plan]
+        self._device_elision_outcome(dev, plan, compared, part_dist)
         declared = size > 1 and hasattr(self.file, 'set_partition')
         if declared:
             if int(part_dist[rank]) != n_local:
@@ -467,8 +491,10 @@ class HOOMDTrajectory(object):
         particle_offset = 'auto' if declared else part_dist
 
         # 2. write, in the reference's chunk order; device fields go out in one fused launch
-        device_fields = []
-        for path, name, write in plan:
+        device_fields = []      # not staged: consecutive GPU-resident fields leave in one fused launch
+        staged_run = []         # staged (one launch for the whole frame, above): consecutive chunk numbers of the ticket
+        dev_at = dict((at, (k, field)) for k, (at, _, field) in enumerate(dev))
+        for at, (path, name, write) in enumerate(plan):
             if not write:
                 continue
             container = getattr(frame, path)
@@ -477,19 +503,26 @@ class HOOMDTrajectory(object):
             logger.debug('writing data chunk: ' + chunk)
             if path == 'particles' and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
                 dt, M = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
+                if at in dev_at:
+                    k, field = dev_at[at]
+                    if ticket is None:
+                        device_fields.append((chunk, field))
+                    else:
+                        if staged_run and staged_run[-1] + 1 != k:
+                            self._flush_staged(ticket, staged_run, particle_offset, rank)
+                        staged_run.append(k)
+                    continue
                 if data is None:
                     # another rank needs the chunk: contribute this rank's rows of the default
                     default = container._default_value.get(name, container._extra_default_value.get(name))
                     data = numpy.empty([n_local] + ([M] if M > 1 else []), dtype=dt)
                     data[...] = default
-                if _is_device(data):
-                    f = data if isinstance(data, fl.DeviceField) else fl.DeviceField.from_tensor(data, out_dtype=dt)
-                    device_fields.append((chunk, f))
-                else:
-                    self._flush_device_fields(device_fields, particle_offset, rank)
-                    self.file.write_chunk(chunk, data, particle_offset, rank, True)
+                self._flush_device_fields(device_fields, particle_offset, rank)
+                self._flush_staged(ticket, staged_run, particle_offset, rank)
+                self.file.write_chunk(chunk, data, particle_offset, rank, True)
                 continue
             self._flush_device_fields(device_fields, particle_offset, rank)
+            self._flush_staged(ticket, staged_run, particle_offset, rank)
             # replicated small chunks (hoomd.py:604-630)
             if name == 'N':
                 count = n_global if path == 'particles' else int(container.N)
@@ -504,6 +537,7 @@ class HOOMDTrajectory(object):
                 data = _encode_strings(data)
             self.file.write_chunk(chunk, data, None, rank, False)
         self._flush_device_fields(device_fields, particle_offset, rank)
+        self._flush_staged(ticket, staged_run, particle_offset, rank)
 
         # state and logged quantities: the sketch calls ``write_chunk(name, data)`` with the binding's
         # default arguments (hoomd.py:634-640; the state loop is commented out twice, upstream GSD
@@ -517,6 +551,106 @@ class HOOMDTrajectory(object):
         self.file.end_frame(wait=wait)
         if declared:
             self.file.set_partition(None)       # the declaration was this frame's
+
+    def _flush_staged(self, ticket, run, part_dist, rank):
+        if run:
+            self.file.write_staged(ticket, run[0], len(run), offset=part_dist, rank=rank)
+            del run[:]
+
+    def _device_elision_votes(self, frame, dev, plan, rank, size, n_local):
+        """The elision test of hoomd.py:654-694 for GPU-resident per-particle arrays, on the GPU.
+
+        All of the frame's GPU-resident arrays are packed by ONE launch into staging (`stage_chunks`); the packed
+        bytes of those that have equalled frame 0 so far are compared with this rank's rows of frame 0 in device
+        memory (`compare_staged`: one kernel, one stream wait) and the equal ones vote "skip" in ``plan``.  Frame 0's
+        rows come from the staging of frame 0 itself when this trajectory wrote it (`copy_staged`: a device-to-device
+        copy), from the file otherwise (`read_chunk_device`, once per array).  An array that differed once is not
+        compared again; a change of the partition ends the comparisons (frame 0's rows are other particles' then).
+        Byte equality: an array holding NaNs is elided when the bits match (numpy.array_equal would write it), +0.0 /
+        -0.0 differ (numpy would elide) -- either way the reader gets the frame's bits.
+
+        Returns ``(ticket, compared)``: the staging ticket (None: nothing staged, the fields leave in fused launches as
+        before) and the positions in ``dev`` that were compared."""
+        f = self.file
+        if not dev or not self.device_elision or self._dev_off or not hasattr(f, 'compare_staged'):
+            return None, []
+        fields = [(chunk, field) for _, chunk, field in dev]
+        if len(self) == 0:
+            # frame 0 itself: written in full; its packed rows stay in HBM for the comparisons to come
+            ticket = f.stage_chunks(fields)
+            sizes = [int(field.N) * int(field.M) * field.out_dtype.itemsize for _, field in fields]
+            self._dev_ref = dict(zip((c for c, _ in fields), f.copy_staged(ticket, 0, sizes)))
+            return ticket, []
+        given = None
+        if frame.part_dist is not None:
+            given = tuple(int(x) for x in numpy.asarray(frame.part_dist).reshape(-1))
+        elif size == 1:
+            given = (n_local,)
+        part = self._dev_ref_part
+        if part is None:
+            # opened on an existing file: rows of frame 0 are read for the partition this frame has -- when the
+            # caller states it (or there is one rank) and frame 0 holds that many particles; otherwise the partition
+            # is only known after this frame's exchange, and the comparisons start with the next frame
+            n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
+            if given is None or n0 is None or int(n0) != sum(given):
+                return None, []
+            part = given
+        elif given is not None and given != part:
+            return None, []                 # (the outcome step sees the change and ends the comparisons)
+        if len(part) != size or part[rank] != n_local:
+            return None, []
+        frame0 = self._frame0_chunks or ()
+        candidates = [k for k, (_, chunk, _) in enumerate(dev) if chunk not in self._dev_dynamic and chunk in frame0]
+        if not candidates:
+            return None, []
+        row0 = sum(part[:rank])
+        ticket = f.stage_chunks(fields)
+        refs = [None] * len(dev)
+        for k in candidates:
+            _, chunk, field = dev[k]
+            ref = self._dev_ref.get(chunk)
+            if ref is None:
+                ref = f.read_chunk_device(0, chunk, N=n_local, offset=row0)
+                self._dev_ref[chunk] = ref
+            if ref.numel() * ref.element_size() == int(field.N) * int(field.M) * field.out_dtype.itemsize:
+                refs[k] = ref
+        equal = f.compare_staged(ticket, 0, refs)
+        for k in candidates:
+            at = dev[k][0]
+            plan[at] = (plan[at][0], plan[at][1], not equal[k])
+        return ticket, candidates
+
+    def _device_elision_outcome(self, dev, plan, compared, part_dist):
+        """After the ranks agreed on ``plan``: book-keeping of `_device_elision_votes` (identical on every rank)."""
+        if not dev or not self.device_elision or self._dev_off:
+            return
+        part = tuple(int(x) for x in part_dist)
+        if self._dev_ref_part is None:
+            # frame 0 just staged (its rows were kept), or the first frame appended to an existing file: the rows
+            # read from frame 0 from now on are those of THIS partition -- if frame 0 has that many particles at all
+            n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
+            if len(self) > 0 and (n0 is None or int(n0) != sum(part)):
+                self._dev_off = True
+            else:
+                self._dev_ref_part = part
+        elif part != self._dev_ref_part:
+            # particles moved between the ranks (or their number changed): whatever was compared was compared with
+            # other particles' rows.  Everything GPU-resident is written, now and from now on
+            self._dev_off = True
+            for at, _, _ in dev:
+                plan[at] = (plan[at][0], plan[at][1], True)
+        if self._dev_off:
+            self._dev_ref.clear()
+            return
+        for k in compared:
+            at, chunk, _ = dev[k]
+            if plan[at][2]:
+                self._dev_dynamic.add(chunk)            # differs from frame 0 (on some rank): a moving array
+                self._dev_ref.pop(chunk, None)
+        if len(self) > 0:
+            # rows of frame 0 kept for arrays this frame did not bring along, or that frame 0 does not hold
+            for chunk in [c for c in self._dev_ref if c in self._dev_dynamic]:
+                del self._dev_ref[chunk]
 
     def _flush_device_fields(self, device_fields, part_dist, rank):
         if device_fields:
@@ -537,6 +671,11 @@ class HOOMDTrajectory(object):
         if self._elision_ref is not None:
             initial_container = getattr(self._elision_ref, path)
             initial_data = getattr(initial_container, name, None)
+            if (initial_data is None and self._elision_lazy and path == 'particles'
+                    and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA)
+                    and (path + '/' + name) in (self._frame0_chunks or ())):
+                initial_data = self.file.read_chunk(frame=0, name=path + '/' + name, offset=numpy.uint32(0), r_all=False)
+                initial_container.__dict__[name] = initial_data
             if initial_data is not None and _equal(initial_data, data):
                 logger.debug('skipping data chunk, matches frame 0: ' + path + '/' + name)
                 return False
@@ -589,6 +728,7 @@ class HOOMDTrajectory(object):
         self.file.close()
         del self._initial_frame
         self._elision_ref = None
+        self._dev_ref = {}
 
     def flush(self):
         """Flush all buffered frames to the file."""

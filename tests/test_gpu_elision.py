@@ -1,0 +1,197 @@
+"""Elision of GPU-resident arrays (hoomd.py:654-694 for arrays that live in HBM): `pgsd_compare_staged_chunks` /
+`pgsd_copy_staged_chunks` against numpy, and `HOOMDTrajectory.append` with device arrays against the same frames
+appended from host arrays -- the files must be identical byte for byte."""
+import numpy as np
+import pytest
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _fields(fl, pos4, vel4, dens):
+    return [("particles/position", fl.DeviceField.from_tensor(pos4, columns=(0, 3))),
+            ("particles/typeid", fl.DeviceField.from_tensor(pos4, columns=(3, 4), out_dtype=np.uint32, bitcast=True)),
+            ("particles/velocity", fl.DeviceField.from_tensor(vel4, columns=(0, 3), out_dtype=np.float32)),
+            ("particles/density", dens)]
+
+
+@pytest.mark.parametrize("N", [0, 1, 1001, 40_000, 1 << 20])
+def test_compare_and_copy_staged_against_numpy(N, tmp_gsd):
+    """1001 rows: the direct (pinned host) staging, tails that are not whole 16-byte vectors; 2^20 rows: HBM staging.
+    A difference in the very last element, in the first, none; a reference that is not 16-byte aligned; no reference."""
+    import pgsd.fl as fl
+    rng = np.random.default_rng(N + 3)
+    pos = rng.standard_normal((N, 4)).astype(np.float32)
+    pos[:, 3] = rng.integers(0, 5, size=N).astype(np.uint32).view(np.float32)
+    vel = rng.standard_normal((N, 4))                                   # float64 source, float32 chunk
+    dens = rng.standard_normal(N).astype(np.float32)
+    dpos, dvel, ddens = dev(pos), dev(vel), dev(dens)
+    packed = [np.ascontiguousarray(pos[:, :3]), np.ascontiguousarray(pos[:, 3]).view(np.uint32),
+              np.ascontiguousarray(vel[:, :3]).astype(np.float32), dens]
+    with fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4]) as f:
+        f.frame_exchange = True
+        t = f.stage_chunks(_fields(fl, dpos, dvel, ddens))
+        refs = f.copy_staged(t, 0, [p.nbytes for p in packed])
+        assert f.compare_staged(t, 0, refs) == [True] * 4               # a chunk equals its own copy
+        for r, p in zip(refs, packed):
+            assert r.cpu().numpy().tobytes() == p.tobytes()             # ... which is the packed chunk
+        f.write_staged(t, 0, 4, offset=np.array([N]))
+        with pytest.raises(RuntimeError):
+            f.compare_staged(t, 0, refs)                                # written chunks are gone
+        f.end_frame()
+        if N == 0:
+            return
+        # frame 1: the last element of the velocity and the first type id change
+        dvel[N - 1, 2] += 1.0
+        dpos[0, 3] = torch.tensor([9], dtype=torch.int32).view(torch.float32)[0]
+        t = f.stage_chunks(_fields(fl, dpos, dvel, ddens))
+        assert f.compare_staged(t, 0, refs) == [True, False, False, True]
+        assert f.compare_staged(t, 1, [None, refs[2]]) == [False, False]
+        # a reference at an odd address: the byte-wise road of the kernel
+        odd = torch.empty(packed[3].nbytes + 4, dtype=torch.uint8, device="cuda")[4:]
+        odd.copy_(refs[3])
+        assert odd.data_ptr() % 16 != 0
+        assert f.compare_staged(t, 3, [odd]) == [True]
+        odd[-1] ^= 1
+        assert f.compare_staged(t, 3, [odd]) == [False]
+        if N > 1:
+            with pytest.raises(ValueError):
+                f.compare_staged(t, 3, [torch.empty(N * 4 + 1, dtype=torch.uint8, device="cuda")])
+        f.write_staged(t, 1, 2, offset=np.array([N]))                   # only what differs is written
+        f.end_frame()                                                   # ... the other two staged chunks are dropped
+    with fl.open(tmp_gsd, "r") as f:
+        assert f.nframes == 2
+        assert not f.chunk_exists(1, "particles/position") and not f.chunk_exists(1, "particles/density")
+        assert f.read_chunk(1, "particles/typeid")[0] == 9
+        assert f.read_chunk(1, "particles/velocity")[N - 1, 2] == np.float32(vel[N - 1, 2] + 1.0)
+
+
+def _frame(hoomd, fl, step, pos, tid, mass, vel, dens, on_gpu, keep):
+    fr = hoomd.Frame()
+    fr.configuration.step = step
+    fr.particles.N = pos.shape[0]
+    fr.particles.types = ["A", "B", "C"]
+    if on_gpu:
+        p4 = np.zeros((pos.shape[0], 4), np.float32)
+        p4[:, :3], p4[:, 3] = pos, tid.view(np.float32)
+        v4 = np.zeros((pos.shape[0], 4), np.float32)
+        v4[:, :3], v4[:, 3] = vel, mass
+        dp, dv, dd = dev(p4), dev(v4), dev(dens)
+        keep += [dp, dv, dd]
+        fr.particles.position = fl.DeviceField.from_tensor(dp, columns=(0, 3))
+        fr.particles.typeid = fl.DeviceField.from_tensor(dp, columns=(3, 4), out_dtype=np.uint32, bitcast=True)
+        fr.particles.velocity = fl.DeviceField.from_tensor(dv, columns=(0, 3))
+        fr.particles.mass = fl.DeviceField.from_tensor(dv, columns=(3, 4))
+        fr.particles.density = dd
+    else:
+        fr.particles.position, fr.particles.typeid, fr.particles.velocity = pos, tid, vel
+        fr.particles.mass, fr.particles.density = mass, dens
+    return fr
+
+
+def _trajectory(rng, N, frames):
+    """Type id and mass never change, the density changes once (frame 2) and goes back, positions always move."""
+    tid = rng.integers(0, 3, size=N).astype(np.uint32)
+    mass = (1.0 + rng.random(N)).astype(np.float32)        # != the default 1.0 anywhere
+    dens0 = (2.0 + rng.random(N)).astype(np.float32)
+    out = []
+    for k in range(frames):
+        dens = dens0 + np.float32(1.0) if k == 2 else dens0
+        out.append((10 * k, rng.standard_normal((N, 3)).astype(np.float32), tid, mass,
+                    rng.standard_normal((N, 3)).astype(np.float32), dens))
+    return out
+
+
+@pytest.mark.parametrize("N", [777, 200_000])
+def test_append_elides_static_gpu_arrays_like_host_arrays(N, tmp_path):
+    """The same frames from GPU-resident and from host arrays: identical files, except that an array that differed once
+    (the density, frame 2) is written from then on by the device path -- so the data here are chosen for identical
+    files up to frame 2 and identical CONTENT after."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(N), N, 5)
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    keep = []
+    for path, on_gpu, upto in ((a, True, 2), (b, False, 2)):
+        with hoomd.open(path, "w") as t:
+            for args in frames[:upto]:
+                t.append(_frame(hoomd, fl, *args, on_gpu, keep))
+            if on_gpu:
+                assert t._dev_dynamic == {"particles/position", "particles/velocity"}
+                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with hoomd.open(a, "w") as t:
+        for args in frames:
+            t.append(_frame(hoomd, fl, *args, True, keep))
+        assert "particles/density" in t._dev_dynamic and not t._dev_off
+    with hoomd.open(a, "r") as t:
+        f = t.file
+        assert [f.chunk_exists(k, "particles/typeid") for k in range(5)] == [True, False, False, False, False]
+        assert [f.chunk_exists(k, "particles/mass") for k in range(5)] == [True, False, False, False, False]
+        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, True, True]
+        assert all(f.chunk_exists(k, "particles/position") for k in range(5))
+        for k, (step, pos, tid, mass, vel, dens) in enumerate(frames):
+            fr = t[k]
+            assert fr.configuration.step == step
+            for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
+                assert getattr(fr.particles, name).tobytes() == want.tobytes(), (k, name)
+
+
+def test_append_device_elision_off_writes_everything(tmp_path):
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(4), 500, 3)
+    path, keep = str(tmp_path / "t.gsd"), []
+    with hoomd.open(path, "w") as t:
+        t.device_elision = False
+        for args in frames:
+            t.append(_frame(hoomd, fl, *args, True, keep))
+    with hoomd.open(path, "r") as t:
+        assert all(t.file.chunk_exists(k, "particles/typeid") for k in range(3))
+
+
+def test_append_to_an_existing_file_compares_with_rows_read_from_frame_0(tmp_path):
+    """Reopened trajectory: frame 0's rows are not in HBM any more, they are read from the file
+    (`read_chunk_device`) -- same files as the host path again."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(8), 3000, 4)
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    keep = []
+    for path, on_gpu in ((a, True), (b, False)):
+        with hoomd.open(path, "w") as t:
+            t.append(_frame(hoomd, fl, *frames[0], on_gpu, keep))
+        with hoomd.open(path, "r+") as t:
+            t.append(_frame(hoomd, fl, *frames[1], on_gpu, keep))
+            if on_gpu:
+                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+
+
+def test_particle_count_change_ends_the_comparisons(tmp_path):
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    rng = np.random.default_rng(2)
+    f3 = _trajectory(rng, 400, 2)
+    other = _trajectory(rng, 300, 1)[0]
+    path, keep = str(tmp_path / "t.gsd"), []
+    with hoomd.open(path, "w") as t:
+        t.append(_frame(hoomd, fl, *f3[0], True, keep))
+        t.append(_frame(hoomd, fl, *f3[1], True, keep))
+        t.append(_frame(hoomd, fl, 99, *other[1:], True, keep))         # 300 particles
+        assert t._dev_off and not t._dev_ref
+        back = (100,) + f3[0][1:]
+        t.append(_frame(hoomd, fl, *back, True, keep))                   # 400 again, equal to frame 0: written all the same
+    with hoomd.open(path, "r") as t:
+        ex = [t.file.chunk_exists(k, "particles/typeid") for k in range(4)]
+        assert ex == [True, False, True, True]
+        assert t[2].particles.N == 300 and t[3].particles.typeid.tobytes() == f3[0][2].tobytes()

@@ -188,10 +188,29 @@ class Model:
             return False
         return True
 
+    def device_votes(self, chunk, name, local, counts, frame_index):
+        """GPU-resident per-particle attribute: frame 0 is written in full; later an array is skipped when every rank's
+        packed rows equal its rows of frame 0 BYTE FOR BYTE -- as long as the partition is frame 0's and the array has
+        not differed before (`HOOMDTrajectory._device_elision_votes`)."""
+        if all(v is None for v in local):
+            return False
+        if frame_index == 0 or self.dev_off or chunk in self.dev_dynamic or chunk not in self.frame0_chunks:
+            return True
+        row0 = [sum(counts[:r]) for r in range(self.P)]
+        init = self.initial["particles"][name]
+        same = all(v is not None and np.ascontiguousarray(init[row0[r]:row0[r] + counts[r]]).tobytes() == v.tobytes()
+                   for r, v in enumerate(local))
+        if not same:
+            self.dev_dynamic.add(chunk)
+        return not same
+
     def append(self, g, counts, frame_index, device=False):
-        """device=True: the per-particle attributes are GPU-resident, which `append` never elides
-        (documented deviation: comparing them would cost a device pass and a sync)."""
+        """device=True: the per-particle attributes are GPU-resident (compared on the GPU: `device_votes`)."""
         P = self.P
+        if device and frame_index == 0:
+            self.dev_counts, self.dev_off, self.dev_dynamic = list(counts), False, set()
+        elif device and list(counts) != self.dev_counts:
+            self.dev_off = True             # particles moved between ranks / their number changed: no more comparisons
         n_global = sum(counts)
         row0 = [sum(counts[:r]) for r in range(P)]
         written = []
@@ -213,7 +232,7 @@ class Model:
                         v = np.ascontiguousarray(v, dtype=np.float32)
                     local.append(v)
                 if device and path == "particles" and name not in REPLICATED:
-                    if all(v is None for v in local):
+                    if not self.device_votes(path + "/" + name, name, local, counts, frame_index):
                         continue
                 elif not any(self.should_write(path, name, local[r], default, frame_index) for r in range(P)):
                     continue

@@ -33,6 +33,7 @@ def frame(i):
 
 
 with H.open(path, "w") as t:
+    t.device_elision = False       # the same tensors every frame: with the comparison on, frames 1.. would be elided
     for i in range(50):
         t.append(frame(i))
     pr = cProfile.Profile()

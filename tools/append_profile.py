@@ -28,6 +28,7 @@ def frame(i):
 
 
 with H.open(path, "w") as t:
+    t.device_elision = False       # the same tensors every frame: with the comparison on, frames 1.. would be elided
     for i in range(5):
         t.append(frame(i))
     torch.cuda.synchronize()
