@@ -195,3 +195,80 @@ def test_particle_count_change_ends_the_comparisons(tmp_path):
         ex = [t.file.chunk_exists(k, "particles/typeid") for k in range(4)]
         assert ex == [True, False, True, True]
         assert t[2].particles.N == 300 and t[3].particles.typeid.tobytes() == f3[0][2].tobytes()
+
+
+# ---------------------------------------------------------------- two ranks: the outcome is agreed
+def _one_sided_frames():
+    """Frame 1: type id, mass, image and density as in frame 0 except ONE density value in the last row (the last
+    rank's); frame 2: everything as in frame 0 again -- the density was written once and is written from then on."""
+    import test_hoomd_append_oracle as A
+    f0 = A.global_frames()[0]
+    n = f0["n"]
+    frames = [f0]
+    for k in (1, 2):
+        p0 = f0["particles"]
+        dens = np.array(p0["density"], dtype=np.float32, copy=True)
+        if k == 1:
+            dens[n - 1] += 1.0
+        g = {"configuration": {"step": 100 + k, "dimensions": None, "box": f0["configuration"]["box"]},
+             "particles": {"types": p0["types"], "typeid": p0["typeid"], "mass": p0["mass"], "image": p0["image"],
+                           "density": dens, "position": np.asarray(p0["position"]) + np.float32(k),
+                           "type_shapes": p0["type_shapes"]},
+             "constraints": f0["constraints"], "log": {}, "state": {}, "n": n}
+        frames.append(g)
+    return frames
+
+
+def _append_rank(rank, P, shm, path, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
+        sys.path.insert(0, os.path.join(root, "tests"))
+        import torch as _t
+        import pgsd.fl as fl
+        import pgsd.hoomd as hoomd
+        from pgsd import _lib
+        import test_gpu_config4 as C4
+        import test_gpu_elision as me
+        import test_hoomd_append_oracle as A
+        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        _t.cuda.set_device(0)
+        t = hoomd.open(path, "w")
+        for g in me._one_sided_frames():
+            t.append(C4._device_frame(hoomd, fl, g, A.partition(g["n"], P), rank))
+        dyn = sorted(t._dev_dynamic)
+        t.close()
+        _lib.lib.pgsd_comm_finalize()
+        q.put((rank, "ok", dyn))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+        raise
+
+
+def test_two_ranks_agree_on_what_is_elided(tmp_path):
+    """A difference in ONE rank's rows: both ranks write the chunk (the vote rides in the frame's allgather), both
+    stop comparing it, and the file is the model's (`device_votes` in tests/test_hoomd_append_oracle.py)."""
+    import multiprocessing as mp
+    import uuid
+    import test_hoomd_append_oracle as A
+    P = 2
+    ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
+    written = A.expected_file(ref, P, device=True, frames=_one_sided_frames())
+    assert "particles/density" in written[1] and "particles/density" in written[2]
+    assert "particles/typeid" not in written[1] and "particles/mass" not in written[2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = "pgsdgpu_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_append_rank, args=(r, P, shm, mine, q)) for r in range(P)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(msg == "ok" for _, msg, _ in results), results
+    assert results[0][2] == results[1][2] == ["particles/density", "particles/position"]
+    with open(mine, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read()
