@@ -272,3 +272,79 @@ def test_two_ranks_agree_on_what_is_elided(tmp_path):
     assert results[0][2] == results[1][2] == ["particles/density", "particles/position"]
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
+
+
+def _reopen_rank(rank, P, shm, path, explicit, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
+        sys.path.insert(0, os.path.join(root, "tests"))
+        import torch as _t
+        import pgsd.fl as fl
+        import pgsd.hoomd as hoomd
+        from pgsd import _lib
+        import test_gpu_elision as me
+        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        _t.cuda.set_device(0)
+        counts = [700, 300]
+        row0 = sum(counts[:rank])
+        frames = me._trajectory(np.random.default_rng(77), sum(counts), 3)
+        keep = []
+
+        def local(args):
+            step, pos, tid, mass, vel, dens = args
+            s = slice(row0, row0 + counts[rank])
+            fr = me._frame(hoomd, fl, step, pos[s], tid[s], mass[s], vel[s], dens[s], True, keep)
+            if explicit:
+                fr.part_dist = np.array(counts, dtype=np.uint64)
+            return fr
+
+        t = hoomd.open(path, "w")
+        t.append(local(frames[0]))
+        t.close()
+        t = hoomd.open(path, "r+")
+        t.append(local(frames[1]))
+        t.append(local(frames[2]))
+        refs = sorted(t._dev_ref)
+        t.close()
+        _lib.lib.pgsd_comm_finalize()
+        q.put((rank, "ok", refs))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+        raise
+
+
+@pytest.mark.parametrize("explicit", [False, True])
+def test_two_ranks_reopened_file_reads_each_ranks_rows_of_frame_0(explicit, tmp_path):
+    """A trajectory reopened by two ranks: frame 0's rows come from the FILE, each rank its own (rank 1 from row 700
+    on).  With the partition stated by the caller (`Frame.part_dist`) the first appended frame is already compared;
+    without, the partition is known after that frame's exchange and the comparisons start with the next one."""
+    import multiprocessing as mp
+    import uuid
+    import pgsd.hoomd as hoomd
+    P = 2
+    path = str(tmp_path / "t.gsd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = "pgsdgpu_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_reopen_rank, args=(r, P, shm, path, explicit, q)) for r in range(P)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(msg == "ok" for _, msg, _ in results), results
+    assert results[0][2] == results[1][2] == ["particles/mass", "particles/typeid"]    # the density moved in frame 2
+    frames = _trajectory(np.random.default_rng(77), 1000, 3)
+    with hoomd.open(path, "r") as t:
+        f = t.file
+        assert [f.chunk_exists(k, "particles/typeid") for k in range(3)] == [True, not explicit, False]
+        assert [f.chunk_exists(k, "particles/density") for k in range(3)] == [True, not explicit, True]
+        assert all(f.chunk_exists(k, "particles/position") for k in range(3))
+        for k, (step, pos, tid, mass, vel, dens) in enumerate(frames):
+            fr = t[k]
+            for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
+                assert getattr(fr.particles, name).tobytes() == want.tobytes(), (k, name)
