@@ -246,6 +246,15 @@ extern "C"
        ONE exchange whatever mix of host and device chunks it holds.  (The reference's contract -- rows borrowed
        for the call -- is the default; pgsd.fl turns this on where it holds the arrays itself.) */
     int pgsd_set_deferred_rows(struct pgsd_handle* handle, int on);
+
+    /* pgsd_read_chunk / pgsd_read_chunk_device on a writable handle flush first like the reference's (pgsd.c:2436
+       -2537): collective, because a rank may read rows another rank wrote.  With `on`, reads are LOCAL: they wait
+       for this rank's own asynchronous copies only and take no part in a collective -- for rows the caller knows to
+       be in the file: its own rows of a sealed frame, or any rows of a file that was opened after they were
+       written.  (pgsd.hoomd reads each rank's rows of frame 0 this way when it first compares an array with them;
+       which arrays a rank compares need not be the same on every rank.)  Chunks of the open frame are not flushed
+       by a local read. */
+    int pgsd_set_local_reads(struct pgsd_handle* handle, int on);
     /* Perform the exchange now (collective; nothing is flushed): afterwards the queue is empty and the
        handle's mirror is current.  No-op when nothing is queued. */
     int pgsd_frame_exchange(struct pgsd_handle* handle);

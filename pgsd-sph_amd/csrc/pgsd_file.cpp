@@ -212,6 +212,7 @@ struct Impl
     // frame-batched exchange: chunk writes that do not need their file offset at once are queued and
     // ONE allgather per frame (at pgsd_end_frame) carries their sizes and the ranks' status
     bool batch = false;
+    bool local_reads = false; // pgsd_set_local_reads: reads drain this rank's own copies only, no collective flush
     bool defer_rows = false; // batched: host rows of all == true chunks stay valid until the exchange (pgsd_set_deferred_rows)
     bool unsynced = false; // a batched frame was sealed that no barrier between the ranks has covered yet
     std::vector<Queued> queue;
@@ -845,6 +846,29 @@ static int flush_for_lookup(Impl* s)
             {
             set_last_error(err);
             remember_failure(s, drc, drc == PGSD_ERROR_IO ? errno : 0); // every rank hears of it at the next flush
+            return drc;
+            }
+        }
+    return PGSD_SUCCESS;
+    }
+
+// What a READ needs before it touches the file: the reference's flush (collective) -- or, with
+// pgsd_set_local_reads, only this rank's own asynchronous copies in place.
+static int flush_for_read(Impl* s)
+    {
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_SUCCESS;
+    if (!s->local_reads)
+        return do_flush(s);
+    if (s->dev && s->inflight)
+        {
+        s->inflight = false;
+        std::string err;
+        const int drc = device_pipeline_drain(s->dev, &err);
+        if (drc != PGSD_SUCCESS)
+            {
+            set_last_error(err);
+            remember_failure(s, drc, drc == PGSD_ERROR_IO ? errno : 0);
             return drc;
             }
         }
@@ -1852,7 +1876,7 @@ extern "C" int pgsd_read_chunk(struct pgsd_handle* handle, void* data, const str
     pgsd_index_entry c = *chunk;
     if (s->flags != PGSD_OPEN_READONLY)
         {
-        int rc = do_flush(s);
+        int rc = flush_for_read(s);
         publish(handle, s);
         if (rc != PGSD_SUCCESS)
             return rc;
@@ -2039,6 +2063,20 @@ extern "C" int pgsd_set_partition(struct pgsd_handle* handle, const uint64_t* ro
         }
     publish(handle, s);
     return rc;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_set_local_reads(struct pgsd_handle* handle, int on)
+    try
+    {
+    Impl* s = impl_of(handle);
+    if (!s)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    s->local_reads = on != 0;
+    return PGSD_SUCCESS;
     }
 catch (...)
     {
@@ -2703,7 +2741,7 @@ extern "C" int pgsd_read_chunk_device(struct pgsd_handle* handle, const struct p
     pgsd_index_entry c = *chunk; // a flush may move the index storage
     if (s->flags != PGSD_OPEN_READONLY)
         {
-        int rc = do_flush(s);
+        int rc = flush_for_read(s);
         publish(handle, s);
         if (rc != PGSD_SUCCESS)
             return rc;

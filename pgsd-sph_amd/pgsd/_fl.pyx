@@ -261,7 +261,7 @@ cdef class PGSDFile:
     cdef bint _is_open
     cdef object _mode, _name, _comm
     cdef list _keepalive, _async_keep
-    cdef bint _explicit_stream, _deferred_rows
+    cdef bint _explicit_stream, _deferred_rows, _local_reads
     cdef object _source_stream
 
     def __init__(self, name, mode, application, schema, schema_version, comm=None):
@@ -304,6 +304,7 @@ cdef class PGSDFile:
         self._explicit_stream = False
         self._source_stream = -1       # what the pipeline was last told (-1: nothing yet)
         self._deferred_rows = False
+        self._local_reads = False
         self._async_keep = []
         memset(&self._handle, 0, sizeof(self._handle))
 
@@ -476,6 +477,23 @@ cdef class PGSDFile:
             err = errno
         _raise_on_error(retval, self._name, err)
         self._deferred_rows = bool(on)
+
+    @property
+    def local_reads(self):
+        """bool: reads on a writable file take no part in a collective flush (``pgsd_set_local_reads``): for rows the
+        caller knows to be in the file -- this rank's own rows of a sealed frame, or a file opened after they were
+        written.  Default False: a read flushes first, collectively, like the reference's (pgsd.c:2436-2537)."""
+        return bool(self._local_reads)
+
+    @local_reads.setter
+    def local_reads(self, on):
+        cdef int retval, err, flag = 1 if on else 0
+        self._check_open()
+        with nogil:
+            retval = C.pgsd_set_local_reads(&self._handle, flag)
+            err = errno
+        _raise_on_error(retval, self._name, err)
+        self._local_reads = bool(on)
 
     def set_partition(self, rows):
         """Declare every rank's row count (``pgsd_set_partition``): while declared, chunk writes exchange nothing --
@@ -902,6 +920,37 @@ cdef class PGSDFile:
             _raise_on_error(retval, self._name, err)
         if eM == 1:
             return data_array.reshape([eN])
+        return data_array
+
+    def read_rows(self, frame, name, row0, n):
+        """Rows ``[row0, row0 + n)`` of a chunk as an ``(n,)`` / ``(n, M)`` numpy array: `pgsd_read_chunk` with
+        ``all == true`` (pgsd.c:2498-2534) into an array of THAT height -- :meth:`read_chunk` with ``r_all=True``
+        allocates the chunk's full height like the reference's binding (fl.pyx:838-860), every rank the global array."""
+        self._check_open()
+        cdef const C.pgsd_index_entry* e = self._find(frame, name)
+        if e == NULL:
+            raise KeyError("frame " + str(frame) + " / chunk " + name + " not found in: " + self._name)
+        cdef uint64_t eN = e.N
+        cdef uint32_t eM = e.M
+        cdef int etype = e.type
+        if etype not in _PGSD_TO_NP:
+            raise ValueError("invalid type for chunk: " + name)
+        if int(row0) < 0 or int(n) < 0 or int(row0) + int(n) > eN or int(row0) >= (1 << 32):
+            raise ValueError("row range outside the chunk: " + name)
+        data_array = numpy.empty(dtype=_PGSD_TO_NP[etype], shape=[int(n), eM])
+        cdef Py_buffer view
+        cdef uint64_t c_N = int(n)
+        cdef uint32_t c_off = int(row0)
+        cdef int retval, err
+        if c_N != 0 and eM != 0:
+            PyObject_GetBuffer(data_array, &view, PyBUF_ANY_CONTIGUOUS)
+            with nogil:
+                retval = C.pgsd_read_chunk(&self._handle, view.buf, e, c_N, eM, c_off, True)
+                err = errno
+            PyBuffer_Release(&view)
+            _raise_on_error(retval, self._name, err)
+        if eM == 1:
+            return data_array.reshape([int(n)])
         return data_array
 
     def read_chunk_device(self, frame, name, out=None, N=None, offset=0, columns=None, order=None,

@@ -199,6 +199,7 @@ _sig("pgsd_set_frame_exchange", c_i32, HP, c_i32)
 _sig("pgsd_get_frame_exchange", c_i32, HP)
 _sig("pgsd_frame_exchange", c_i32, HP)
 _sig("pgsd_set_deferred_rows", c_i32, HP, c_i32)
+_sig("pgsd_set_local_reads", c_i32, HP, c_i32)
 _sig("pgsd_set_partition", c_i32, HP, ctypes.POINTER(c_u64), c_u32)
 _sig("pgsd_get_collective_count", c_u64, HP)
 _sig("pgsd_get_exchange_stats", c_i32, HP, ctypes.POINTER(ExchangeStats), c_i32)

@@ -335,6 +335,7 @@ class HOOMDTrajectory(object):
         self._dev_ref_part = None      # the partition (every rank's row count) those rows belong to
         self._dev_dynamic = set()      # GPU-resident chunks seen to differ from frame 0: not compared any more
         self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
+        self._host_ref = {}            # several ranks: chunk -> this rank's rows of frame 0 (host arrays are compared too)
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
             raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
@@ -441,6 +442,7 @@ class HOOMDTrajectory(object):
         #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes
         plan = []
         dev = []        # GPU-resident per-particle attributes: (index in plan, chunk name, DeviceField), schema order
+        host_pp = []    # several ranks: per-particle HOST arrays that would be written: (index in plan, chunk name, array)
         for path in ('configuration', 'particles', 'constraints'):
             container = getattr(frame, path)
             names = list(container._default_value)
@@ -461,9 +463,14 @@ class HOOMDTrajectory(object):
                     dev.append((len(plan), path + '/' + name, field))
                     plan.append((path, name, True))
                 else:
-                    plan.append((path, name, self._should_write(path, name, frame, None)))
+                    write = self._should_write(path, name, frame, None)
+                    if write and size > 1 and path == 'particles' and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
+                        host_pp.append((len(plan), path + '/' + name, value))
+                    plan.append((path, name, write))
         n_local = int(frame.particles.N) if frame.particles.N is not None else 0
-        ticket, compared = self._device_elision_votes(frame, dev, plan, rank, size, n_local)
+        part0 = self._frame0_partition(frame, dev or host_pp, rank, size, n_local)
+        self._host_elision_votes(host_pp, plan, part0, rank, n_local)
+        ticket, compared = self._device_elision_votes(dev, plan, part0, rank, n_local)
         if frame.part_dist is not None:
             part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
             if part_dist.shape[0] != size:
@@ -482,7 +489,7 @@ class HOOMDTrajectory(object):
         n_global = int(part_dist.sum())
         plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') and w else w)
                 for p, n, w in plan]
-        self._device_elision_outcome(dev, plan, compared, part_dist)
+        self._elision_outcome(dev, host_pp, plan, compared, part0, part_dist)
         declared = size > 1 and hasattr(self.file, 'set_partition')
         if declared:
             if int(part_dist[rank]) != n_local:
@@ -557,7 +564,66 @@ class HOOMDTrajectory(object):
             self.file.write_staged(ticket, run[0], len(run), offset=part_dist, rank=rank)
             del run[:]
 
-    def _device_elision_votes(self, frame, dev, plan, rank, size, n_local):
+    def _frame0_partition(self, frame, wanted, rank, size, n_local):
+        """The partition (every rank's row count) for which this rank's rows of frame 0 are, or can be, at hand -- or
+        None when per-particle arrays cannot be compared with frame 0 in this frame: nothing to compare, frame 0
+        itself, the comparisons ended (`_dev_off`), a partition that differs from the one the rows were taken for,
+        or one that is not known before the frame's exchange (no `Frame.part_dist`, several ranks, first frame
+        appended to an existing file: the comparisons then start with the next frame)."""
+        if not wanted or self._dev_off or len(self) == 0:
+            return None
+        given = None
+        if frame.part_dist is not None:
+            given = tuple(int(x) for x in numpy.asarray(frame.part_dist).reshape(-1))
+        elif size == 1:
+            given = (n_local,)
+        part = self._dev_ref_part
+        if part is None:
+            n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
+            if given is None or n0 is None or int(n0) != sum(given):
+                return None
+            part = given
+        elif given is not None and given != part:
+            return None                     # (`_elision_outcome` sees the change and ends the comparisons)
+        if len(part) != size or part[rank] != n_local:
+            return None
+        return part
+
+    def _read_frame0_rows(self, chunk, row0, n, device):
+        """This rank's rows ``[row0, row0 + n)`` of a per-particle chunk of frame 0, as a numpy array or a GPU tensor.
+        A LOCAL read (`PGSDFile.local_reads`): these are rows this rank wrote itself in this session, or rows of a
+        file that was complete when it was opened -- and which arrays a rank compares need not be the same on every
+        rank, so the read must not be a collective."""
+        f = self.file
+        before = f.local_reads
+        f.local_reads = True
+        try:
+            if device:
+                return f.read_chunk_device(0, chunk, N=n, offset=row0)
+            return f.read_rows(0, chunk, row0, n)
+        finally:
+            f.local_reads = before
+
+    def _host_elision_votes(self, host_pp, plan, part0, rank, n_local):
+        """Several ranks: a per-particle HOST array is compared with THIS RANK'S rows of frame 0 (read from the file
+        when first needed, ``numpy.array_equal`` as on one rank); equal rows vote "skip".  (Compared with the whole of
+        frame 0 -- every rank's rows -- as the sketch has it, hoomd.py:673-687, an array could never be equal.)"""
+        if not host_pp or part0 is None:
+            return
+        frame0 = self._frame0_chunks or ()
+        row0 = sum(part0[:rank])
+        for at, chunk, data in host_pp:
+            if chunk not in frame0:
+                continue
+            ref = self._host_ref.get(chunk)
+            if ref is None:
+                ref = self._read_frame0_rows(chunk, row0, n_local, False)
+                self._host_ref[chunk] = ref
+            if _equal(ref, data):
+                logger.debug('skipping data chunk, this rank\'s rows match frame 0: ' + chunk)
+                plan[at] = (plan[at][0], plan[at][1], False)
+
+    def _device_elision_votes(self, dev, plan, part0, rank, n_local):
         """The elision test of hoomd.py:654-694 for GPU-resident per-particle arrays, on the GPU.
 
         All of the frame's GPU-resident arrays are packed by ONE launch into staging (`stage_chunks`); the packed
@@ -581,36 +647,20 @@ class HOOMDTrajectory(object):
             sizes = [int(field.N) * int(field.M) * field.out_dtype.itemsize for _, field in fields]
             self._dev_ref = dict(zip((c for c, _ in fields), f.copy_staged(ticket, 0, sizes)))
             return ticket, []
-        given = None
-        if frame.part_dist is not None:
-            given = tuple(int(x) for x in numpy.asarray(frame.part_dist).reshape(-1))
-        elif size == 1:
-            given = (n_local,)
-        part = self._dev_ref_part
-        if part is None:
-            # opened on an existing file: rows of frame 0 are read for the partition this frame has -- when the
-            # caller states it (or there is one rank) and frame 0 holds that many particles; otherwise the partition
-            # is only known after this frame's exchange, and the comparisons start with the next frame
-            n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
-            if given is None or n0 is None or int(n0) != sum(given):
-                return None, []
-            part = given
-        elif given is not None and given != part:
-            return None, []                 # (the outcome step sees the change and ends the comparisons)
-        if len(part) != size or part[rank] != n_local:
+        if part0 is None:
             return None, []
         frame0 = self._frame0_chunks or ()
         candidates = [k for k, (_, chunk, _) in enumerate(dev) if chunk not in self._dev_dynamic and chunk in frame0]
         if not candidates:
             return None, []
-        row0 = sum(part[:rank])
+        row0 = sum(part0[:rank])
         ticket = f.stage_chunks(fields)
         refs = [None] * len(dev)
         for k in candidates:
             _, chunk, field = dev[k]
             ref = self._dev_ref.get(chunk)
             if ref is None:
-                ref = f.read_chunk_device(0, chunk, N=n_local, offset=row0)
+                ref = self._read_frame0_rows(chunk, row0, n_local, True)
                 self._dev_ref[chunk] = ref
             if ref.numel() * ref.element_size() == int(field.N) * int(field.M) * field.out_dtype.itemsize:
                 refs[k] = ref
@@ -620,14 +670,15 @@ class HOOMDTrajectory(object):
             plan[at] = (plan[at][0], plan[at][1], not equal[k])
         return ticket, candidates
 
-    def _device_elision_outcome(self, dev, plan, compared, part_dist):
-        """After the ranks agreed on ``plan``: book-keeping of `_device_elision_votes` (identical on every rank)."""
-        if not dev or not self.device_elision or self._dev_off:
+    def _elision_outcome(self, dev, host_pp, plan, compared, part0, part_dist):
+        """After the ranks agreed on ``plan``: book-keeping of the comparisons with this rank's rows of frame 0
+        (`_host_elision_votes`, `_device_elision_votes`); identical on every rank."""
+        if self._dev_off:
             return
         part = tuple(int(x) for x in part_dist)
         if self._dev_ref_part is None:
-            # frame 0 just staged (its rows were kept), or the first frame appended to an existing file: the rows
-            # read from frame 0 from now on are those of THIS partition -- if frame 0 has that many particles at all
+            # frame 0 being written, or the first frame appended to an existing file: the rows of frame 0 kept / read
+            # from now on are those of THIS partition -- if frame 0 has that many particles at all
             n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
             if len(self) > 0 and (n0 is None or int(n0) != sum(part)):
                 self._dev_off = True
@@ -635,22 +686,20 @@ class HOOMDTrajectory(object):
                 self._dev_ref_part = part
         elif part != self._dev_ref_part:
             # particles moved between the ranks (or their number changed): whatever was compared was compared with
-            # other particles' rows.  Everything GPU-resident is written, now and from now on
+            # other particles' rows.  Every per-particle array that is set is written, now and from now on
             self._dev_off = True
-            for at, _, _ in dev:
-                plan[at] = (plan[at][0], plan[at][1], True)
+            if part0 is not None:
+                for at, _, _ in list(dev) + list(host_pp):
+                    plan[at] = (plan[at][0], plan[at][1], True)
         if self._dev_off:
             self._dev_ref.clear()
+            self._host_ref.clear()
             return
         for k in compared:
             at, chunk, _ = dev[k]
             if plan[at][2]:
                 self._dev_dynamic.add(chunk)            # differs from frame 0 (on some rank): a moving array
                 self._dev_ref.pop(chunk, None)
-        if len(self) > 0:
-            # rows of frame 0 kept for arrays this frame did not bring along, or that frame 0 does not hold
-            for chunk in [c for c in self._dev_ref if c in self._dev_dynamic]:
-                del self._dev_ref[chunk]
 
     def _flush_device_fields(self, device_fields, part_dist, rank):
         if device_fields:
@@ -729,6 +778,7 @@ class HOOMDTrajectory(object):
         del self._initial_frame
         self._elision_ref = None
         self._dev_ref = {}
+        self._host_ref = {}
 
     def flush(self):
         """Flush all buffered frames to the file."""

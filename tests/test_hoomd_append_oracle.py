@@ -142,6 +142,7 @@ class Model:
         assert rc.value == 0
         self.initial = None          # frame 0 as a READER sees it (global, defaults filled in)
         self.frame0_chunks = set()
+        self.part_off = False
 
     def small(self, name, arr):
         """write_all=False, offset=None: every rank passes the same value (fl.pyx:592-598)"""
@@ -172,12 +173,16 @@ class Model:
         assert S.oracle_write_chunk(self.lib, self.h, name, t, arrs, M, Ng, M, [x * M for x in row0], [Ng * M] * self.P,
                                     True) == 0
 
-    def should_write(self, path, name, data, default, frame_index):
-        """hoomd.py:654-694 for ONE rank's value `data` (None = not set)."""
+    def should_write(self, path, name, data, default, frame_index, rows=None):
+        """hoomd.py:654-694 for ONE rank's value `data` (None = not set).  rows: with several ranks a per-particle
+        array is compared with THAT RANK'S rows of frame 0 (`HOOMDTrajectory._host_elision_votes`) -- while the
+        partition is frame 0's; against the whole of frame 0, as the sketch compares, it could never be equal."""
         if data is None:
             return False
         if self.initial is not None:
             init = self.initial[path].get(name)
+            if rows is not None and init is not None:
+                init = init[rows] if (not self.part_off and (path + "/" + name) in self.frame0_chunks) else None
             if init is not None and np.array_equal(init, data):
                 return False
         if name in ("types", "type_shapes"):
@@ -207,10 +212,15 @@ class Model:
     def append(self, g, counts, frame_index, device=False):
         """device=True: the per-particle attributes are GPU-resident (compared on the GPU: `device_votes`)."""
         P = self.P
+        if frame_index == 0:
+            self.counts0, self.part_off = list(counts), False
+        elif list(counts) != self.counts0:
+            self.part_off = True            # particles moved between ranks / their number changed: frame 0's rows are
+                                            # other particles' from now on (several ranks: no more comparisons)
         if device and frame_index == 0:
             self.dev_counts, self.dev_off, self.dev_dynamic = list(counts), False, set()
         elif device and list(counts) != self.dev_counts:
-            self.dev_off = True             # particles moved between ranks / their number changed: no more comparisons
+            self.dev_off = True             # the same for GPU-resident arrays (one rank too)
         n_global = sum(counts)
         row0 = [sum(counts[:r]) for r in range(P)]
         written = []
@@ -234,7 +244,10 @@ class Model:
                 if device and path == "particles" and name not in REPLICATED:
                     if not self.device_votes(path + "/" + name, name, local, counts, frame_index):
                         continue
-                elif not any(self.should_write(path, name, local[r], default, frame_index) for r in range(P)):
+                elif not any(self.should_write(path, name, local[r], default, frame_index,
+                                               slice(row0[r], row0[r] + counts[r])
+                                               if P > 1 and path == "particles" and name not in REPLICATED else None)
+                             for r in range(P)):
                     continue
                 chunk = path + "/" + name
                 written.append(chunk)
@@ -362,3 +375,46 @@ def test_append_multi_rank_matches_oracle_file(P, tmp_path):
         np.testing.assert_array_equal(t[1].particles.typeid, frames[0]["particles"]["typeid"])
         assert t[2].particles.N == 17 and t[2].particles.types == ["A", "Bb", "C"]
         np.testing.assert_array_equal(t[1].log["energy"], [3.5, -4.5])
+
+
+def _lopsided_worker(rank, world, port, path):
+    sys.path.insert(0, os.path.join(S.ROOT, "pgsd-sph_amd"))
+    sys.path.insert(0, os.path.join(S.ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pgsd.dist as pdist
+    import pgsd.hoomd as hoomd
+    assert pdist.init_from_torch() == "torch-gloo"
+    counts = [0, 6]                         # rank 0 holds no particles: it has no rows of frame 0 to read
+    t = hoomd.open(path, "w")
+    for k in range(4):
+        fr = hoomd.Frame()
+        fr.configuration.step = k
+        fr.particles.N = counts[rank]
+        fr.particles.position = np.full((counts[rank], 3), k + 1, np.float32)
+        fr.particles.density = np.full(counts[rank], 7.0 if k != 2 else 8.0, np.float32)
+        t.append(fr, wait=(k % 2 == 0))
+    t.close()
+    pdist.finalize()
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_rows_is_not_waited_for_by_the_others_reads(tmp_path):
+    """Rank 1 compares its arrays with its rows of frame 0 and reads them from the file when it first does; rank 0
+    holds no particles and reads nothing.  Those reads are LOCAL (`PGSDFile.local_reads`): as the collective flush a
+    read on a writable handle is by default (pgsd.c:2436-2537), rank 1 would wait in one rank 0 never enters."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from test_multirank import free_port
+    import pgsd.hoomd as hoomd
+    path = str(tmp_path / "t.gsd")
+    mp.spawn(_lopsided_worker, args=(2, free_port(), path), nprocs=2, join=True)
+    with hoomd.open(path, "r") as t:
+        f = t.file
+        assert [f.chunk_exists(k, "particles/density") for k in range(4)] == [True, False, True, False]
+        assert all(f.chunk_exists(k, "particles/position") for k in range(4))
+        np.testing.assert_array_equal(t[2].particles.density, [8] * 6)
+        np.testing.assert_array_equal(t[3].particles.density, [7] * 6)
+        np.testing.assert_array_equal(t[3].particles.position, np.full((6, 3), 4, np.float32))
