@@ -390,6 +390,8 @@ class HOOMDTrajectory(object):
         * the write/skip decision of every chunk is agreed over the ranks (written if any rank needs
           it; a rank without a value contributes the default for its rows), because a chunk write is
           collective; ``particles/N`` is compared as the global count;
+        * with several ranks a per-particle host array is compared with THIS rank's rows of frame 0
+          (`_host_elision_votes`; against the whole of frame 0, as the sketch compares, it could never be equal);
         * GPU-resident per-particle arrays are compared with frame 0 ON THE GPU (`device_elision`, default on;
           `_device_elision_votes`): packed by one launch, their packed bytes compared with this rank's rows of frame 0
           in device memory, the equal ones elided like host arrays -- byte equality, frame 0 itself always written
