@@ -23,5 +23,10 @@ for n in 1024 16384; do
   PGSD_TRACE=1 timeout -k 10 200 rocprofv3 --hip-trace --kernel-trace --marker-trace --stats --output-format csv -d $O/trace_$n -- python3 $GRAFT_REPO_ROOT/tools/append_trace.py $n 100 > $O/trace_$n.log 2>&1
   python3 $GRAFT_REPO_ROOT/tools/phase_timeline.py $O/trace_$n 60 > $O/phase_timeline_append_$n.txt 2>&1
 done
+# elision of GPU-resident arrays: the comparison kernel under the profiler (duration, FETCH_SIZE, WRITE_SIZE), then the tool's own run
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/elision_stats -- python3 $GRAFT_REPO_ROOT/tools/elision_bench.py --no-append > $O/elision_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/elision_fetch -- python3 $GRAFT_REPO_ROOT/tools/elision_bench.py --no-append > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/elision_write -- python3 $GRAFT_REPO_ROOT/tools/elision_bench.py --no-append > /dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"
+timeout -k 10 300 python tools/elision_bench.py > $O/elision_bench.log 2>&1; echo "elision bench rc=$?" | tee -a $O/summary.txt
 cat $O/summary.txt; tail -1 $O/bench_n1.json | cut -c1-600; tail -12 $O/phase_timeline_10M.txt
