@@ -457,3 +457,33 @@ def test_open_modes(tmp_path):
     for mode in ('w', 'x'):                                # creating needs the metadata (fl.pyx:327-334)
         with pytest.raises(ValueError):
             fl.open(name=str(tmp_path / "nometa.gsd"), mode=mode)
+
+
+def test_read_rows_and_local_reads(tmp_gsd):
+    """`read_rows`: a row range into an array of that height (pgsd_read_chunk with all == true, pgsd.c:2498-2534);
+    `local_reads`: reads on a writable handle that take no part in a collective flush (pgsd_set_local_reads)."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((1000, 3)).astype(np.float32)
+    b = rng.integers(0, 9, size=1000).astype(np.uint32)
+    with fl.open(tmp_gsd, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        f.write_chunk('particles/position', a)
+        f.write_chunk('particles/typeid', b)
+        f.end_frame()
+        f.write_chunk('particles/position', a + 1)
+        f.end_frame()
+        assert f.local_reads is False
+        f.local_reads = True
+        assert f.local_reads is True
+        got = f.read_rows(0, 'particles/position', 250, 100)
+        assert got.shape == (100, 3) and got.tobytes() == a[250:350].tobytes()
+        assert f.read_rows(0, 'particles/typeid', 999, 1).tobytes() == b[999:].tobytes()
+        assert f.read_rows(1, 'particles/position', 0, 1000).tobytes() == (a + 1).tobytes()
+        assert f.read_rows(0, 'particles/typeid', 1000, 0).shape == (0,)
+        f.local_reads = False
+        assert f.read_rows(0, 'particles/position', 0, 3).tobytes() == a[:3].tobytes()
+        with pytest.raises(ValueError):
+            f.read_rows(0, 'particles/position', 990, 11)
+        with pytest.raises(KeyError):
+            f.read_rows(2, 'particles/position', 0, 1)
+    with fl.open(tmp_gsd, 'r') as f:
+        assert f.read_rows(0, 'particles/position', 1, 2).tobytes() == a[1:3].tobytes()
