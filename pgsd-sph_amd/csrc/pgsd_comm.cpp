@@ -198,6 +198,7 @@ struct ShmSegment
     uint32_t generation;
     uint32_t broken;
     int32_t pids[SHM_MAX_RANKS];
+    uint64_t want[SHM_MAX_RANKS]; // bytes per rank of the allgather each rank is in: ranks out of step are told so
     char pad[64];
     // followed by size * SHM_SLOT_BYTES slot bytes
     };
@@ -209,6 +210,7 @@ struct ShmCtx
     size_t map_bytes;
     std::string name;
     int rank, size;
+    bool told = false; // this rank has been given the reason why the communicator is broken
     };
 
 // no such process, or a zombie nobody has reaped yet
@@ -244,7 +246,13 @@ static int shm_barrier(void* p)
     ShmCtx* c = (ShmCtx*)p;
     ShmSegment* seg = c->seg;
     if (__atomic_load_n(&seg->broken, __ATOMIC_ACQUIRE))
+        {
+        if (!c->told)
+            set_last_error("the shm communicator is broken: a collective failed on another rank (ranks in different "
+                           "collectives, or a rank gone)");
+        c->told = true;
         return -1;
+        }
     const uint32_t gen = __atomic_load_n(&seg->generation, __ATOMIC_ACQUIRE);
     if (__atomic_add_fetch(&seg->arrived, 1, __ATOMIC_ACQ_REL) == (uint32_t)c->size)
         {
@@ -274,6 +282,7 @@ static int shm_barrier(void* p)
                 {
                 __atomic_store_n(&seg->broken, 1, __ATOMIC_RELEASE);
                 set_last_error("a rank of the shm communicator is gone (process exited without pgsd_comm_finalize)");
+                c->told = true;
                 return -1;
                 }
             }
@@ -288,12 +297,30 @@ static int shm_allgather(void* p, const void* send, void* recv, size_t bytes)
     char* r = (char*)recv;
     // messages larger than a slot go in rounds
     size_t done = 0;
+    __atomic_store_n(&c->seg->want[c->rank], (uint64_t)bytes, __ATOMIC_RELAXED);
     do
         {
         size_t n = bytes - done < (size_t)SHM_SLOT_BYTES ? bytes - done : (size_t)SHM_SLOT_BYTES;
         memcpy(c->slots + (size_t)c->rank * SHM_SLOT_BYTES, s + done, n);
         if (shm_barrier(p) != 0)
             return -1;
+        if (done == 0)
+            {
+            // Every rank must be in the SAME collective: a rank that made a call the others did not (a collective
+            // read on one rank only, say) would otherwise pair its message with a different exchange of theirs and
+            // every rank would go on with the other's bytes.  All ranks see the same vector, so all fail alike.
+            // (a rank that has found the mismatch already may be in its next call, its size overwritten: `broken`)
+            for (int j = 0; j < c->size; j++)
+                if (__atomic_load_n(&c->seg->want[j], __ATOMIC_RELAXED) != (uint64_t)bytes
+                    || __atomic_load_n(&c->seg->broken, __ATOMIC_ACQUIRE))
+                    {
+                    c->told = true;
+                    set_last_error("the ranks are in different collectives (message sizes differ): a collective call "
+                                   "was made by some ranks only");
+                    __atomic_store_n(&c->seg->broken, 1, __ATOMIC_RELEASE);
+                    return -1;
+                    }
+            }
         for (int j = 0; j < c->size; j++)
             memcpy(r + (size_t)j * bytes + done, c->slots + (size_t)j * SHM_SLOT_BYTES, n);
         if (shm_barrier(p) != 0)

@@ -88,6 +88,52 @@ def test_a_dead_peer_is_an_error_not_a_hang():
             pass
 
 
+OUT_OF_STEP = r'''
+import sys, os, ctypes
+sys.path.insert(0, %r)
+import pgsd.dist as d
+from pgsd import _lib
+rank = int(sys.argv[2])
+d.init_shm(sys.argv[1], rank, 2)
+d.partition_rows(5)                   # one good exchange
+n = 8 if rank == 0 else 16            # rank 0 is in one collective, rank 1 in another
+send = (ctypes.c_uint8 * n)()
+recv = (ctypes.c_uint8 * (2 * n))()
+rc = _lib.lib.pgsd_comm_allgather(send, recv, n)
+print(rc, _lib.last_error())
+try:
+    d.partition_rows(5)               # the communicator is broken for good: no rank goes on with the other's bytes
+    print("NO ERROR")
+except RuntimeError as e:
+    print("then:", e)
+d.finalize()
+''' % os.path.join(ROOT, "pgsd-sph_amd")
+
+
+def test_ranks_in_different_collectives_are_told_so():
+    """A collective call made by some ranks only (a collective read on one rank, say) would pair its message with a
+    different exchange of the others; the shm allgather compares the message sizes and fails on EVERY rank."""
+    name = "pgsd_step_%s" % uuid.uuid4().hex[:10]
+    try:
+        ps = [subprocess.Popen([sys.executable, "-c", OUT_OF_STEP, name, str(r)], stdout=subprocess.PIPE) for r in (0, 1)]
+        outs = []
+        try:
+            for p in ps:
+                outs.append(p.communicate(timeout=60)[0].decode().strip().splitlines())
+        finally:
+            for p in ps:
+                if p.poll() is None:
+                    p.kill()
+        for out in outs:
+            assert out[0].startswith("-") and "different collectives" in out[0], outs
+            assert out[1].startswith("then:"), outs
+    finally:
+        try:
+            os.unlink("/dev/shm/" + name)
+        except OSError:
+            pass
+
+
 def test_eight_ranks_as_threads_of_one_process_on_per_handle_communicators(tmp_path):
     """`pgsd_comm_create_shm` + `pgsd_create_and_open_on`: communicators that are not the process default, one per
     thread, eight ranks in ONE process writing config 3's chunk sequence from host arrays -- the file is the
