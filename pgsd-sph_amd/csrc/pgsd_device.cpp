@@ -650,20 +650,33 @@ class DevicePipeline
         if (jobs.empty())
             return PGSD_SUCCESS;
         TraceRange tr("pgsd:compare chunks=%llu", (unsigned long long)jobs.size(), 0ull);
+        // (each step on its own: a call that failed half-way is picked up where it stopped by the next one)
         if (!m_cmp_host)
             {
             void* h = nullptr;
-            void* hd = nullptr;
-            void* d = nullptr;
             HIP_TRY(hipHostMalloc(&h, CMP_MAX_JOBS * sizeof(uint32_t), hipHostMallocMapped));
             memset(h, 0, CMP_MAX_JOBS * sizeof(uint32_t));
             m_cmp_host = (uint32_t*)h;
-            HIP_TRY(hipHostGetDevicePointer(&hd, h, 0));
+            }
+        if (!m_cmp_host_dev)
+            {
+            void* hd = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&hd, m_cmp_host, 0));
             m_cmp_host_dev = (uint32_t*)hd;
+            }
+        if (!m_cmp_dev)
+            {
+            void* d = nullptr;
             HIP_TRY(hipMalloc(&d, CMP_MAX_JOBS * sizeof(uint32_t)));
-            m_cmp_dev = (uint32_t*)d;
             // on the stream the kernels run on: a null-stream memset is not ordered with a non-blocking stream
-            HIP_TRY(hipMemsetAsync(d, 0, CMP_MAX_JOBS * sizeof(uint32_t), m_pack_stream));
+            hipError_t me = hipMemsetAsync(d, 0, CMP_MAX_JOBS * sizeof(uint32_t), m_pack_stream);
+            if (me != hipSuccess)
+                {
+                (void)hipFree(d);
+                fail(std::string("hipMemsetAsync: ") + hipGetErrorString(me));
+                return PGSD_ERROR_DEVICE;
+                }
+            m_cmp_dev = (uint32_t*)d;
             }
         for (size_t at = 0; at < jobs.size(); at += CMP_MAX_JOBS)
             {
