@@ -336,6 +336,8 @@ class HOOMDTrajectory(object):
         self._dev_dynamic = set()      # GPU-resident chunks seen to differ from frame 0: not compared any more
         self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
         self._host_ref = {}            # several ranks: chunk -> this rank's rows of frame 0 (host arrays are compared too)
+        self._frame0_dev_part = None   # read_frame_device: the partition whose rows of frame 0 are kept in HBM ...
+        self._frame0_dev_cache = {}    # ... chunk -> GPU tensor
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
         if self.file.schema != 'hoomd':
             raise RuntimeError('PGSD file is not a hoomd schema file: ' + str(self.file))
@@ -781,6 +783,7 @@ class HOOMDTrajectory(object):
         self._elision_ref = None
         self._dev_ref = {}
         self._host_ref = {}
+        self._frame0_dev_cache = {}
 
     def flush(self):
         """Flush all buffered frames to the file."""
@@ -952,6 +955,9 @@ class HOOMDTrajectory(object):
         snap.part = (row0, n)
 
         specs = list(_PARTICLE_SPEC.items()) + list(_PARTICLE_SPEC_EXTRA.items())
+        if self._frame0_dev_part != (row0, n):
+            self._frame0_dev_part, self._frame0_dev_cache = (row0, n), {}     # rows of ONE partition are kept
+        cache, fresh = self._frame0_dev_cache, []
         n_frame0 = None          # frame 0's arrays stand in only while the particle count is frame 0's (hoomd.py:858-884)
         default_rows = None      # this read's own copy of the default rows (one small device-to-device copy, below)
         for name, (dt, M) in specs:
@@ -962,7 +968,17 @@ class HOOMDTrajectory(object):
                     n_frame0 = int(f.read_chunk(0, 'particles/N')[0]) if f.chunk_exists(0, 'particles/N') else n_global
                 if n_frame0 != n_global:
                     fr = None
-            if fr is not None:
+            if fr == 0 and idx != 0:
+                # an array the frame does not hold because it equals frame 0's (elided by `append`): this partition's
+                # rows of frame 0 are read from the file ONCE and handed out as device-to-device copies from then on
+                # (a trajectory whose static arrays are elided would otherwise re-read them for every frame)
+                cached = cache.get(chunk)
+                if cached is not None:
+                    setattr(snap.particles, name, cached.clone())
+                else:
+                    setattr(snap.particles, name, f.read_chunk_device(0, chunk, N=n, offset=row0, wait=False))
+                    fresh.append((name, chunk))
+            elif fr is not None:
                 setattr(snap.particles, name, f.read_chunk_device(fr, chunk, N=n, offset=row0, wait=False))
             elif name in snap.particles._default_value:
                 # like the host reader (hoomd.py:872-881) a default is ONE row broadcast over the particles: no
@@ -995,6 +1011,8 @@ class HOOMDTrajectory(object):
                     arr[:, 3] = w_default
             snap.particles.pos4, snap.particles.vel4 = pos4, vel4
         f.wait_read()
+        for name, chunk in fresh:
+            cache[chunk] = getattr(snap.particles, name).clone()
         for log in f.find_matching_chunk_names('log/', False):
             fr = frame_of(log)
             if fr is not None:

@@ -348,3 +348,31 @@ def test_two_ranks_reopened_file_reads_each_ranks_rows_of_frame_0(explicit, tmp_
             fr = t[k]
             for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
                 assert getattr(fr.particles, name).tobytes() == want.tobytes(), (k, name)
+
+
+def test_device_reader_keeps_frame_0_rows_of_elided_arrays(tmp_path):
+    """`read_frame_device` on a trajectory whose static arrays were elided: the rows of frame 0 are read from the file
+    once and handed out as copies -- changing what a read returned changes nothing a later read returns."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(12), 6000, 4)
+    path, keep = str(tmp_path / "t.gsd"), []
+    with hoomd.open(path, "w") as t:
+        for args in frames:
+            t.append(_frame(hoomd, fl, *args, True, keep))
+    with hoomd.open(path, "r") as t:
+        assert not t.file.chunk_exists(3, "particles/typeid")
+        for sweep in range(2):
+            for k in (1, 2, 3, 0, 3):
+                step, pos, tid, mass, vel, dens = frames[k]
+                fr = t.read_frame_device(k, part=(1000, 4000))
+                s = slice(1000, 5000)
+                for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
+                    got = getattr(fr.particles, name)
+                    assert got.cpu().numpy().tobytes() == want[s].tobytes(), (sweep, k, name)
+                fr.particles.typeid.zero_()                 # the caller's copy, not the trajectory's
+                fr.particles.mass.fill_(-1.0)
+            assert set(t._frame0_dev_cache) == {"particles/typeid", "particles/mass", "particles/density"}
+        fr = t.read_frame_device(1, part=(0, 6000))         # another partition: its own rows
+        assert fr.particles.typeid.cpu().numpy().tobytes() == frames[0][2].tobytes()
+        assert t._frame0_dev_part == (0, 6000) and set(t._frame0_dev_cache) == {"particles/typeid", "particles/mass", "particles/density"}
