@@ -425,6 +425,33 @@ def main():
         payload_bpp, algo_bpp = 164, 328
         layout = "HOOMD-SPH device arrays + upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom)"
 
+    # The run appends world x (warmup + steps [+ 3 stall-test frames]) frames to ONE file: 2.24 GB per frame at eight
+    # ranks.  A target without that much room would end the run in ENOSPC half-way (a tmpfs is also memory of the
+    # job): rank 0 looks first and, when --dir is too small, takes the first of /tmp and the working directory that
+    # is not -- the workload string names the directory that was used.
+    need = world * (args.warmup + args.steps + 4) * N * payload_bpp + (256 << 20)
+    choice = [args.dir]
+    if rank == 0:
+        import shutil
+        for cand in (args.dir, "/tmp", os.getcwd()):
+            try:
+                if shutil.disk_usage(cand).free >= need * 1.05 and os.access(cand, os.W_OK):
+                    choice = [cand]
+                    break
+            except OSError:
+                continue
+        else:
+            choice = [None]
+    if world > 1:
+        dist.broadcast_object_list(choice, src=0)
+    if choice[0] is None:
+        raise SystemExit("bench.py: the run writes %.1f GB (%d ranks x %d frames x %.2f GB) and neither %s, /tmp nor the "
+                         "working directory has that much room: fewer --steps, or --dir <larger target>"
+                         % (need / 1e9, world, args.warmup + args.steps + 4, N * payload_bpp / 1e9, args.dir))
+    if choice[0] != args.dir:
+        print("bench.py: %s has less than the %.1f GB the run writes: writing to %s instead"
+              % (args.dir, need / 1e9, choice[0]), file=sys.stderr)
+        args.dir = choice[0]
     path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
     f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
     f.configure_device(device=local_rank, slab_bytes=args.slab_mib << 20, n_slabs=args.slabs,
