@@ -731,6 +731,7 @@ cdef class PGSDFile:
         cdef uint64_t N = 0, ticket = 0
         cdef int retval, err
         names = []
+        sizes = []
         try:
             for i in range(n):
                 name, data = fields[i]
@@ -746,13 +747,14 @@ cdef class PGSDFile:
                 reqs[i].M = <uint32_t>f.M
                 f.fill_desc(&reqs[i].src)
                 self._keepalive.append(f)
+                sizes.append(int(f.N) * int(f.M) * f.out_dtype.itemsize)
             with nogil:
                 retval = C.pgsd_stage_chunks_device(&self._handle, <uint32_t>n, reqs, N, &ticket)
                 err = errno
         finally:
             free(reqs)
         _raise_on_error(retval, self._name, err)
-        return (int(ticket), int(N))
+        return (int(ticket), int(N), tuple(sizes))      # (ticket, rows, packed bytes of every chunk)
 
     def write_staged(self, ticket, first, count, offset=None, rank=0):
         """Write chunks ``[first, first + count)`` of a :meth:`stage_chunks` ticket at this point of the frame
@@ -794,8 +796,10 @@ cdef class PGSDFile:
                     continue
                 if not _is_device_tensor(r) or not r.is_contiguous():
                     raise ValueError("a reference must be a contiguous torch GPU tensor (or None)")
-                if rows > 0 and (r.numel() * r.element_size()) % rows != 0:
-                    raise ValueError("reference %d does not hold %d rows" % (i, rows))
+                if first + i >= len(ticket[2]) or r.numel() * r.element_size() != ticket[2][first + i]:
+                    # the kernel reads as many bytes of the reference as the packed chunk has: never fewer at hand
+                    raise ValueError("reference %d must hold the %d bytes of the packed chunk"
+                                     % (i, ticket[2][first + i] if first + i < len(ticket[2]) else -1))
                 p = r.data_ptr()
                 # an empty tensor has no address: any non-null one says "there is a reference" (no byte is read)
                 ptrs[i] = <const void*>p if p != 0 else <const void*>ptrs
@@ -817,6 +821,10 @@ cdef class PGSDFile:
         cdef Py_ssize_t n = len(sizes), i
         if n == 0:
             return []
+        for i in range(n):
+            if sizes[i] is not None and (first + i >= len(ticket[2]) or int(sizes[i]) != ticket[2][first + i]):
+                raise ValueError("chunk %d of the ticket has %d packed bytes" % (first + i, ticket[2][first + i]
+                                                                                 if first + i < len(ticket[2]) else -1))
         cdef uint64_t c_ticket = ticket[0]
         cdef uint32_t c_first = first, c_count = n
         cdef void** ptrs = <void**>calloc(n, sizeof(void*))
