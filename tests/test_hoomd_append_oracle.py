@@ -307,7 +307,7 @@ def expected_file(path, P, device=False, frames=None):
     m = Model(path, P)
     chunks = []
     for k, g in enumerate(frames if frames is not None else global_frames()):
-        chunks.append(m.append(g, partition(g["n"], P), k, device=device))
+        chunks.append(m.append(g, g.get("counts") or partition(g["n"], P), k, device=device))
     m.close()
     return chunks
 
@@ -418,3 +418,81 @@ def test_a_rank_without_rows_is_not_waited_for_by_the_others_reads(tmp_path):
         np.testing.assert_array_equal(t[2].particles.density, [8] * 6)
         np.testing.assert_array_equal(t[3].particles.density, [7] * 6)
         np.testing.assert_array_equal(t[3].particles.position, np.full((6, 3), 4, np.float32))
+
+
+# ------------------------------------------------------------------ random trajectories on several ranks
+def random_frames(seed, P):
+    """Global frames whose per-particle arrays never change, always change or change once; the partition changes once
+    in some trajectories (the same particles, other counts per rank: the comparisons with frame 0 end there)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(P, 40))
+    nframes = int(rng.integers(3, 6))
+    names = {"position": (np.float32, 3), "velocity": (np.float32, 3), "typeid": (np.uint32, 1), "mass": (np.float32, 1),
+             "density": (np.float32, 1), "image": (np.int32, 3)}
+    picked = [nm for nm in names if rng.random() < 0.8] or ["position"]
+    behaviour = {nm: rng.choice(["static", "moving", "once"]) for nm in picked}
+    once_at = {nm: int(rng.integers(1, nframes)) for nm in picked}
+    repartition_at = int(rng.integers(1, nframes)) if rng.random() < 0.4 else None
+
+    def values(nm, k):
+        dt, M = names[nm]
+        shape = (n, M) if M > 1 else (n,)
+        v = rng.integers(1, 50, size=shape) + 100 * k       # never a default, never an earlier frame's values
+        return v.astype(dt)
+
+    base = {nm: values(nm, 0) for nm in picked}
+    changed = {}
+    counts = partition(n, P)
+    frames = []
+    for k in range(nframes):
+        if repartition_at is not None and k == repartition_at:
+            counts = list(reversed(counts)) if counts != list(reversed(counts)) else [counts[0] - 1] + counts[1:-1] + [counts[-1] + 1]
+        particles = {}
+        for nm in picked:
+            b = behaviour[nm]
+            if k == 0 or b == "static":
+                particles[nm] = changed.get(nm, base[nm])
+            elif b == "moving":
+                particles[nm] = values(nm, k)
+            else:
+                if k == once_at[nm]:
+                    changed[nm] = values(nm, k)
+                particles[nm] = changed.get(nm, base[nm])
+        frames.append({"configuration": {"step": k, "dimensions": None, "box": [5, 5, 5, 0, 0, 0]},
+                       "particles": particles, "constraints": {}, "log": {}, "state": {}, "n": n,
+                       "counts": list(counts), "explicit": bool(rng.random() < 0.5)})
+    return frames
+
+
+def _random_worker(rank, world, port, path, seed):
+    sys.path.insert(0, os.path.join(S.ROOT, "pgsd-sph_amd"))
+    sys.path.insert(0, os.path.join(S.ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pgsd.dist as pdist
+    import pgsd.hoomd as hoomd
+    import test_hoomd_append_oracle as me
+    assert pdist.init_from_torch() == "torch-gloo"
+    t = hoomd.open(path, "w")
+    for k, g in enumerate(me.random_frames(seed, world)):
+        t.append(me.build_frame(hoomd, g, g["counts"], rank, explicit_part_dist=g["explicit"]), wait=(k % 2 == 0))
+    t.close()
+    pdist.finalize()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,P", [(1, 2), (3, 3), (4, 3), (6, 3), (8, 2), (9, 3), (13, 2), (23, 3)])
+def test_random_multi_rank_trajectories_match_the_model(seed, P, tmp_path):
+    """Host arrays on several ranks: static arrays are elided as on one rank (each rank against its own rows of frame
+    0), until the partition changes; the file is the model's, byte for byte."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from test_multirank import free_port
+    ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
+    frames = random_frames(seed, P)
+    written = expected_file(ref, P, frames=frames)
+    mp.spawn(_random_worker, args=(P, free_port(), mine, seed), nprocs=P, join=True)
+    with open(mine, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read(), written
