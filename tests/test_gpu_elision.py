@@ -376,3 +376,57 @@ def test_device_reader_keeps_frame_0_rows_of_elided_arrays(tmp_path):
         fr = t.read_frame_device(1, part=(0, 6000))         # another partition: its own rows
         assert fr.particles.typeid.cpu().numpy().tobytes() == frames[0][2].tobytes()
         assert t._frame0_dev_part == (0, 6000) and set(t._frame0_dev_cache) == {"particles/typeid", "particles/mass", "particles/density"}
+
+
+def _random_rank(rank, P, shm, path, seed, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
+        sys.path.insert(0, os.path.join(root, "tests"))
+        import torch as _t
+        import pgsd.fl as fl
+        import pgsd.hoomd as hoomd
+        from pgsd import _lib
+        import test_gpu_config4 as C4
+        import test_hoomd_append_oracle as A
+        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        _t.cuda.set_device(0)
+        t = hoomd.open(path, "w")
+        for k, g in enumerate(A.random_frames(seed, P)):
+            fr = C4._device_frame(hoomd, fl, g, g["counts"], rank)
+            if g["explicit"]:
+                fr.part_dist = np.array(g["counts"], dtype=np.uint64)
+            t.append(fr, wait=(k % 2 == 1))
+        t.close()
+        _lib.lib.pgsd_comm_finalize()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("seed,P", [(1, 2), (8, 2), (9, 3), (13, 2), (23, 3), (4, 3)])
+def test_random_multi_rank_device_trajectories_match_the_model(seed, P, tmp_path):
+    """The random trajectories of tests/test_hoomd_append_oracle.py with every per-particle array in HBM, two or three
+    ranks sharing the GPU: the file is the model's (`device_votes`: byte equality on every rank, an array that
+    differed once written from then on, the comparisons ending with a change of the partition)."""
+    import multiprocessing as mp
+    import uuid
+    import test_hoomd_append_oracle as A
+    ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
+    A.expected_file(ref, P, device=True, frames=A.random_frames(seed, P))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = "pgsdgpu_%s" % uuid.uuid4().hex[:10]
+    procs = [ctx.Process(target=_random_rank, args=(r, P, shm, mine, seed, q)) for r in range(P)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(msg == "ok" for _, msg in results), results
+    with open(mine, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read()
