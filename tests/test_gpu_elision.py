@@ -430,3 +430,29 @@ def test_random_multi_rank_device_trajectories_match_the_model(seed, P, tmp_path
     assert all(msg == "ok" for _, msg in results), results
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
+
+
+def test_byte_equality_nan_and_signed_zero(tmp_path):
+    """The GPU comparison is of BYTES: a static array holding NaNs is elided (numpy.array_equal would write it:
+    NaN != NaN), +0.0 against -0.0 is written (numpy would elide).  Either way the reader gets the frame's bits."""
+    import pgsd.hoomd as hoomd
+    N = 300
+    dens = np.linspace(1, 2, N).astype(np.float32)
+    dens[7] = np.nan
+    energy0 = np.full(N, 3.0, np.float32)
+    energy0[5] = 0.0
+    energy1 = energy0.copy()
+    energy1[5] = -0.0
+    path = str(tmp_path / "t.gsd")
+    with hoomd.open(path, "w") as t:
+        for k, energy in enumerate((energy0, energy1)):
+            fr = hoomd.Frame()
+            fr.configuration.step = k
+            fr.particles.N = N
+            fr.particles.density = dev(dens)
+            fr.particles.energy = dev(energy)
+            t.append(fr)
+    with hoomd.open(path, "r") as t:
+        assert not t.file.chunk_exists(1, "particles/density") and t.file.chunk_exists(1, "particles/energy")
+        assert t[1].particles.density.tobytes() == dens.tobytes()
+        assert t[1].particles.energy.tobytes() == energy1.tobytes() != energy0.tobytes()
