@@ -318,6 +318,14 @@ class HOOMDTrajectory(object):
 
     Args:
         file (`pgsd.fl.PGSDFile` or `pgsd.pypgsd.PGSDFile`): file to access.
+
+    Attributes:
+        device_elision (bool): `append` compares GPU-resident per-particle arrays with frame 0 on the GPU and does
+            not write the equal ones (default True; False: GPU-resident arrays are always written).
+
+    Per-particle attributes of a `Frame` may be numpy arrays, torch GPU tensors or `pgsd.fl.DeviceField` views of
+    GPU memory (a column range of a ``Scalar4`` array, a converted or bit-cast element type); `append` writes the
+    GPU-resident ones through the fused pack kernel, `read_frame_device` restores a partition into GPU arrays.
     """
 
     def __init__(self, file):
