@@ -456,3 +456,35 @@ def test_byte_equality_nan_and_signed_zero(tmp_path):
         assert not t.file.chunk_exists(1, "particles/density") and t.file.chunk_exists(1, "particles/energy")
         assert t[1].particles.density.tobytes() == dens.tobytes()
         assert t[1].particles.energy.tobytes() == energy1.tobytes() != energy0.tobytes()
+
+
+def test_long_trajectory_with_reopen_matches_the_host_path(tmp_path):
+    """240 frames -- several relocations of the on-disk index, asynchronous seals among them, the trajectory closed
+    and reopened twice (frame 0's rows then come from the file) -- with GPU-resident arrays and with host arrays:
+    the same file."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    rng = np.random.default_rng(31)
+    N = 1500
+    tid = rng.integers(0, 3, size=N).astype(np.uint32)
+    mass = (1.0 + rng.random(N)).astype(np.float32)
+    dens = (2.0 + rng.random(N)).astype(np.float32)
+    frames = [(k, rng.standard_normal((N, 3)).astype(np.float32), tid, mass,
+               rng.standard_normal((N, 3)).astype(np.float32), dens) for k in range(240)]
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    keep = []
+    for path, on_gpu in ((a, True), (b, False)):
+        for lo, hi, mode in ((0, 90, "w"), (90, 170, "r+"), (170, 240, "r+")):
+            with hoomd.open(path, mode) as t:
+                for k in range(lo, hi):
+                    fr = _frame(hoomd, fl, *frames[k], on_gpu, keep)
+                    fr.log["step_sq"] = np.array([float(k * k)])
+                    t.append(fr, wait=(k % 4 != 1) if on_gpu else True)
+                if on_gpu:
+                    t.file.frame_sync()
+            del keep[:]
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with hoomd.open(a, "r") as t:
+        assert len(t) == 240 and not t.file.chunk_exists(239, "particles/mass")
+        assert t[239].particles.mass.tobytes() == mass.tobytes() and t[200].log["step_sq"][0] == 40000.0
