@@ -488,3 +488,33 @@ def test_long_trajectory_with_reopen_matches_the_host_path(tmp_path):
     with hoomd.open(a, "r") as t:
         assert len(t) == 240 and not t.file.chunk_exists(239, "particles/mass")
         assert t[239].particles.mass.tobytes() == mass.tobytes() and t[200].log["step_sq"][0] == 40000.0
+
+
+def test_elision_by_hand_as_integration_md_shows_it(tmp_gsd):
+    """The snippet of INTEGRATION.md section 3, as written there."""
+    import pgsd.fl as fl
+    N = 5000
+    pos4 = torch.rand((N, 4), device="cuda")
+    mass = torch.rand((N,), device="cuda")
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    frame0 = None
+    for k in range(3):
+        if k:
+            pos4[:, :3] += 1.0
+        fields = [("particles/position", fl.DeviceField.from_tensor(pos4, columns=(0, 3))), ("particles/mass", mass)]
+        first_frame = k == 0
+        t = f.stage_chunks(fields)
+        if first_frame:
+            frame0 = f.copy_staged(t, 0, list(t[2]))
+            same = [False] * len(fields)
+        else:
+            same = f.compare_staged(t, 0, frame0)
+        for i, s in enumerate(same):
+            if not s:
+                f.write_staged(t, i, 1, offset="auto")
+        f.end_frame()
+        assert same == ([False, False] if first_frame else [False, True])
+    f.close()
+    with fl.open(tmp_gsd, "r") as g:
+        assert g.nframes == 3 and g.chunk_exists(2, "particles/position") and not g.chunk_exists(2, "particles/mass")
+        assert g.read_chunk(2, "particles/position").tobytes() == pos4[:, :3].contiguous().cpu().numpy().tobytes()
