@@ -830,15 +830,11 @@ static bool metadata_pending(const Impl* s)
     return work;
     }
 
-static int flush_for_lookup(Impl* s)
+// local: this rank's rows of the asynchronously sealed frames reach the file (documented in pgsd.h)
+static int drain_own_copies(Impl* s)
     {
-    if (s->flags == PGSD_OPEN_READONLY)
-        return PGSD_SUCCESS;
-    if (metadata_pending(s))
-        return do_flush(s);
     if (s->dev && s->inflight)
         {
-        // local: this rank's rows of the asynchronously sealed frames reach the file (documented in pgsd.h)
         s->inflight = false;
         std::string err;
         const int drc = device_pipeline_drain(s->dev, &err);
@@ -852,6 +848,15 @@ static int flush_for_lookup(Impl* s)
     return PGSD_SUCCESS;
     }
 
+static int flush_for_lookup(Impl* s)
+    {
+    if (s->flags == PGSD_OPEN_READONLY)
+        return PGSD_SUCCESS;
+    if (metadata_pending(s))
+        return do_flush(s);
+    return drain_own_copies(s);
+    }
+
 // What a READ needs before it touches the file: the reference's flush (collective) -- or, with
 // pgsd_set_local_reads, only this rank's own asynchronous copies in place.
 static int flush_for_read(Impl* s)
@@ -860,19 +865,7 @@ static int flush_for_read(Impl* s)
         return PGSD_SUCCESS;
     if (!s->local_reads)
         return do_flush(s);
-    if (s->dev && s->inflight)
-        {
-        s->inflight = false;
-        std::string err;
-        const int drc = device_pipeline_drain(s->dev, &err);
-        if (drc != PGSD_SUCCESS)
-            {
-            set_last_error(err);
-            remember_failure(s, drc, drc == PGSD_ERROR_IO ? errno : 0);
-            return drc;
-            }
-        }
-    return PGSD_SUCCESS;
+    return drain_own_copies(s);
     }
 
 // chunks that were staged ahead (pgsd_stage_chunks_device) and never written: their packed bytes go nowhere
