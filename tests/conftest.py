@@ -15,16 +15,20 @@ def _build_if_missing():
     library; this only saves the `python -c "import __graft_entry__ as g; g.build()"` step."""
     import subprocess
     import glob
+    from product import locked_make
     lib = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
     drv = os.path.join(ROOT, "pgsd-sph_amd", "csrc", "build", "scenario_driver")
     ext = glob.glob(os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "_fl.*.so"))      # the Cython file layer (pgsd.fl)
+    # always `make` (a no-op when up to date), under the session's lock: with pytest-xdist every worker passes here
+    # before it runs anything, so a library or driver is never relinked while another worker executes it
+    locked_make(["-C", os.path.join(ROOT, "pgsd-sph_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     if not (os.path.exists(lib) and os.path.exists(drv) and ext):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pgsd-sph_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+        raise RuntimeError("make did not produce libpgsd_amd.so / scenario_driver / the pgsd.fl extension")
     if not os.path.exists(os.path.join(ROOT, "oracle", "libpgsd_oracle.so")):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+        locked_make(["-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):
-        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL,
-                        stderr=subprocess.DEVNULL)      # only where the reference and MPICH exist
+        locked_make(["-C", os.path.join(ROOT, "oracle"), "ref"], check=False, stdout=subprocess.DEVNULL,
+                    stderr=subprocess.DEVNULL)          # only where the reference and MPICH exist
 
 
 def pytest_configure(config):

@@ -11,11 +11,25 @@ DRIVER = os.path.join(CSRC, "build", "scenario_driver")
 _built = False
 
 
+def locked_make(args, check=True, **kw):
+    """`make <args>` under ONE lock for the whole test session: pytest-xdist workers (and the fixtures of different
+    test modules) would otherwise relink a library or a driver that another worker is loading or running
+    ("Text file busy", half-written objects)."""
+    import fcntl
+    import tempfile
+    with open(os.path.join(tempfile.gettempdir(), "pgsd_amd_tests_make_%d.lock" % os.getuid()), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make"] + list(args), **kw)
+    if check and r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, ["make"] + list(args))
+    return r
+
+
 def build():
     """make -C pgsd-sph_amd/csrc (no-op when up to date)."""
     global _built
     if not _built:
-        subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
+        locked_make(["-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
         _built = True
     return LIB
 

@@ -116,8 +116,8 @@ def oracle_lib():
     so = os.path.join(ROOT, "oracle", "libpgsd_oracle.so")
     src = os.path.join(ROOT, "oracle", "pgsd_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"],
-                              stdout=subprocess.DEVNULL)
+        from product import locked_make
+        locked_make(["-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     lib.oracle_create_and_open.restype = vp

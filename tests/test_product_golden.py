@@ -59,7 +59,7 @@ def mpi_driver():
     if not (os.path.exists(MPIEXEC) and os.path.exists("/opt/conda/include/mpi.h")):
         pytest.skip("no MPI installation in this image")
     product.build()
-    r = subprocess.run(["make", "-C", product.CSRC, "mpi"], capture_output=True)
+    r = product.locked_make(["-C", product.CSRC, "mpi"], check=False, capture_output=True)
     if r.returncode != 0:
         pytest.skip("cannot link against MPI: " + r.stderr.decode()[-300:])
     return MPI_DRIVER

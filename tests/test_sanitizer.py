@@ -1,7 +1,6 @@
 """Host file layer under AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available on the
 pool): the scenario driver built with -fsanitize=address,undefined replays golden scenarios with one
 process per rank; no report may appear and the files must still match the goldens."""
-import fcntl
 import os
 import subprocess
 import uuid
@@ -15,11 +14,7 @@ ASAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_asan")
 
 
 def _make(target):
-    """`make <target>` under a file lock: pytest-xdist workers would otherwise relink a binary another one is running."""
-    os.makedirs(os.path.join(product.CSRC, "build"), exist_ok=True)
-    with open(os.path.join(product.CSRC, "build", ".sanitizer_build.lock"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        return subprocess.run(["make", "-C", product.CSRC, target], capture_output=True)
+    return product.locked_make(["-C", product.CSRC, target], check=False, capture_output=True)
 
 
 @pytest.fixture(scope="module")
