@@ -518,3 +518,48 @@ def test_elision_by_hand_as_integration_md_shows_it(tmp_gsd):
     with fl.open(tmp_gsd, "r") as g:
         assert g.nframes == 3 and g.chunk_exists(2, "particles/position") and not g.chunk_exists(2, "particles/mass")
         assert g.read_chunk(2, "particles/position").tobytes() == pos4[:, :3].contiguous().cpu().numpy().tobytes()
+
+
+def test_four_ranks_as_threads_append_through_pgsd_hoomd(tmp_path):
+    """`HOOMDTrajectory.append` on per-handle communicators: four ranks as four THREADS of this process (one
+    communicator and one file object each, all on cuda:0), arrays in HBM, the elision votes riding in each frame's
+    one allgather -- the file is the model's."""
+    import threading
+    import uuid
+    import pgsd.dist as pdist
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    import test_gpu_config4 as C4
+    import test_hoomd_append_oracle as A
+    P, seed = 4, 13
+    ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
+    frames = A.random_frames(seed, P)
+    A.expected_file(ref, P, device=True, frames=frames)
+    shm = "pgsdthr_%s" % uuid.uuid4().hex[:10]
+    errors = []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            comm = pdist.create_shm(shm, rank, P)
+            f = fl.open(mine, "w", application="pgsd.hoomd 3.2.0", schema="hoomd", schema_version=[1, 4], comm=comm)
+            t = hoomd.HOOMDTrajectory(f)
+            for k, g in enumerate(frames):
+                fr = C4._device_frame(hoomd, fl, g, g["counts"], rank)
+                if g["explicit"]:
+                    fr.part_dist = np.array(g["counts"], dtype=np.uint64)
+                t.append(fr, wait=(k % 2 == 0))
+            t.close()
+            pdist.release(comm)
+        except Exception:  # pragma: no cover
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors and not any(th.is_alive() for th in threads), errors
+    with open(mine, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read()
