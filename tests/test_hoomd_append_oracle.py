@@ -496,3 +496,41 @@ def test_random_multi_rank_trajectories_match_the_model(seed, P, tmp_path):
     mp.spawn(_random_worker, args=(P, free_port(), mine, seed), nprocs=P, join=True)
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read(), written
+
+
+def test_four_ranks_as_threads_append_host_arrays(tmp_path):
+    """`HOOMDTrajectory.append` on per-handle communicators (`pgsd.dist.create_shm` + `pgsd.fl.open(comm=)`): four
+    ranks as four threads of this process, host arrays, every C call made without the GIL -- the model's file."""
+    import threading
+    import uuid
+    import pgsd.dist as pdist
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    P, seed = 4, 9
+    ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
+    frames = random_frames(seed, P)
+    expected_file(ref, P, frames=frames)
+    shm = "pgsdthr_%s" % uuid.uuid4().hex[:10]
+    errors = []
+
+    def rank_main(rank):
+        try:
+            comm = pdist.create_shm(shm, rank, P)
+            f = fl.open(mine, "w", application="pgsd.hoomd 3.2.0", schema="hoomd", schema_version=[1, 4], comm=comm)
+            t = hoomd.HOOMDTrajectory(f)
+            for k, g in enumerate(frames):
+                t.append(build_frame(hoomd, g, g["counts"], rank, explicit_part_dist=g["explicit"]))
+            t.close()
+            pdist.release(comm)
+        except Exception:  # pragma: no cover
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors and not any(th.is_alive() for th in threads), errors
+    with open(mine, "rb") as a, open(ref, "rb") as b:
+        assert a.read() == b.read()
