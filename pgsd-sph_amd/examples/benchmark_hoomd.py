@@ -62,9 +62,9 @@ def run(N, size, path, mode):
             for i in range(nframes):
                 if mode == "host":
                     position[0, 0] = i          # every frame differs from frame 0 (benchmark-hoomd.py:27-28):
-                    orientation[0, 0] = i       # nothing is elided.  Arrays in HBM are never compared, hence never
-                                                # elided, and a simulation changes them with kernels of its own, not
-                                                # with a per-frame torch scalar store from the host (~20 us each)
+                    orientation[0, 0] = i       # nothing is elided.  For the arrays in HBM the comparison is switched
+                                                # off above instead: a simulation changes them with kernels of its own,
+                                                # not with a per-frame torch scalar store from the host (~20 us each)
                     hf.append(make_frame(i, position, orientation))
                 elif mode == "hbm-via-host":
                     pos_h, ori_h = position.cpu().numpy(), orientation.cpu().numpy()

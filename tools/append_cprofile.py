@@ -25,7 +25,7 @@ def frame(i):
     f.particles.N = N
     f.configuration.step = i
     if host:
-        pos[0, 0] = i       # both arrays differ from frame 0 every frame: nothing is elided (device arrays never are)
+        pos[0, 0] = i       # both arrays differ from frame 0 every frame: nothing is elided (for device arrays the comparison is switched off below)
         ori[0, 0] = i
     f.particles.position = pos
     f.particles.orientation = ori
