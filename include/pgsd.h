@@ -452,7 +452,9 @@ extern "C"
        ref[i] -- device memory holding the same rows of the other frame as the chunk stores them, N * M *
        sizeof(type) bytes (read with pgsd_read_chunk_device, or kept with pgsd_copy_staged_chunks) -- and sets
        equal[i] = 1 when every byte matches, 0 when not or when ref[i] is NULL (a rank without rows: 1).  One
-       kernel launch behind the pack, one stream wait; local, no collective: the caller agrees the outcome over
+       kernel launch behind the pack -- and behind whatever the caller's source stream (pgsd_device_set_source_stream)
+       holds, like the pack itself: the references may have been written there a moment ago --, one stream wait;
+       local, no collective: the caller agrees the outcome over
        the ranks like any other write / skip decision and then writes (pgsd_write_staged_chunks) or does not
        (unwritten chunks are dropped by pgsd_end_frame).  Byte equality: NaNs with equal bits are equal, -0.0 and
        0.0 are not -- eliding is always safe, a reader gets the same bits back from frame 0.

@@ -439,6 +439,22 @@ class DevicePipeline
         return true;
         }
 
+    // order the pack stream after whatever the caller enqueued on its source stream -- an event there and a wait
+    // here, unless that stream has nothing in flight (one query instead of two calls: small frames)
+    int order_after_source()
+        {
+        if (hipStreamQuery(m_source_stream) != hipSuccess)
+            {
+            (void)hipGetLastError(); // hipErrorNotReady is the answer, not an error
+            hipEvent_t ready = get_event(false);
+            if (!ready)
+                return PGSD_ERROR_DEVICE;
+            HIP_TRY(hipEventRecord(ready, m_source_stream));
+            HIP_TRY(hipStreamWaitEvent(m_pack_stream, ready, 0));
+            }
+        return PGSD_SUCCESS;
+        }
+
     // Pack now, place later.  stage() packs the chunks into the staging arena with one fused launch and
     // returns a ticket; commit() tells where chunk `index` of the ticket goes -- a file offset (asynchronous
     // copy + pwrite), a host buffer (synchronous copy: small replicated chunks headed for the write
@@ -485,17 +501,9 @@ class DevicePipeline
             bytes_out += bytes;
             }
 
-        // order the pack after whatever the caller enqueued on its source stream -- an event there and a wait
-        // here, unless that stream has nothing in flight (one query instead of two calls: small frames)
-        if (hipStreamQuery(m_source_stream) != hipSuccess)
-            {
-            (void)hipGetLastError(); // hipErrorNotReady is the answer, not an error
-            hipEvent_t ready = get_event(false);
-            if (!ready)
-                return PGSD_ERROR_DEVICE;
-            HIP_TRY(hipEventRecord(ready, m_source_stream));
-            HIP_TRY(hipStreamWaitEvent(m_pack_stream, ready, 0));
-            }
+        int orc = order_after_source();
+        if (orc != PGSD_SUCCESS)
+            return orc;
 
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (m_cfg.profile)
@@ -650,6 +658,10 @@ class DevicePipeline
         if (jobs.empty())
             return PGSD_SUCCESS;
         TraceRange tr("pgsd:compare chunks=%llu", (unsigned long long)jobs.size(), 0ull);
+        // the reference bytes may have been produced on the caller's stream a moment ago
+        int orc = order_after_source();
+        if (orc != PGSD_SUCCESS)
+            return orc;
         // (each step on its own: a call that failed half-way is picked up where it stopped by the next one)
         if (!m_cmp_host)
             {

@@ -776,6 +776,8 @@ cdef class PGSDFile:
         (:meth:`read_chunk_device`, :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  One kernel behind the
         pack, one stream wait (``pgsd_compare_staged_chunks``).  Byte equality.  Returns a list of bool."""
         self._check_open()
+        if not self._explicit_stream:
+            self._sync_source_stream()      # the comparison is ordered behind this stream's writes to the references
         cdef Py_ssize_t n = len(refs), i
         if n == 0:
             return []
