@@ -320,8 +320,12 @@ class HOOMDTrajectory(object):
         file (`pgsd.fl.PGSDFile` or `pgsd.pypgsd.PGSDFile`): file to access.
 
     Attributes:
-        device_elision (bool): `append` compares GPU-resident per-particle arrays with frame 0 on the GPU and does
-            not write the equal ones (default True; False: GPU-resident arrays are always written).
+        device_elision: `append` compares GPU-resident per-particle arrays with frame 0 on the GPU and does not
+            write the equal ones.  True (default): an array that differed once is written from then on without a
+            comparison (a moving array costs nothing after the first frame); ``'exact'``: every array is compared in
+            every frame, as host arrays are -- an array that returns to frame 0's values is elided again, at the price
+            of one frame's worth of HBM for the rows of frame 0 and a comparison launch per frame; False:
+            GPU-resident arrays are always written.
 
     Per-particle attributes of a `Frame` may be numpy arrays, torch GPU tensors or `pgsd.fl.DeviceField` views of
     GPU memory (a column range of a ``Scalar4`` array, a converted or bit-cast element type); `append` writes the
@@ -707,6 +711,8 @@ class HOOMDTrajectory(object):
             self._dev_ref.clear()
             self._host_ref.clear()
             return
+        if self.device_elision == 'exact':
+            return                                      # every array is compared in every frame, like host arrays
         for k in compared:
             at, chunk, _ = dev[k]
             if plan[at][2]:

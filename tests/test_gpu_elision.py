@@ -563,3 +563,24 @@ def test_four_ranks_as_threads_append_through_pgsd_hoomd(tmp_path):
     assert not errors and not any(th.is_alive() for th in threads), errors
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
+
+
+def test_exact_mode_elides_an_array_that_returns_to_frame_0(tmp_path):
+    """`device_elision = 'exact'`: no array is ever taken off the comparisons, so the density that differs in frame 2
+    only is elided again from frame 3 on -- the host path's file for all five frames."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(21), 4000, 5)
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    keep = []
+    for path, on_gpu in ((a, True), (b, False)):
+        with hoomd.open(path, "w") as t:
+            t.device_elision = 'exact'
+            for args in frames:
+                t.append(_frame(hoomd, fl, *args, on_gpu, keep))
+            if on_gpu:
+                assert not t._dev_dynamic and len(t._dev_ref) == 5
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with hoomd.open(a, "r") as t:
+        assert [t.file.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, False, False]

@@ -46,14 +46,25 @@ def _to_device(fl, name, a, keep):
 
 @pytest.mark.parametrize("seed", range(SEEDS))
 def test_random_trajectories_match_the_host_path(seed, tmp_path):
+    _run(seed, tmp_path, exact=False)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_trajectories_exact_mode(seed, tmp_path):
+    """`device_elision = 'exact'`: arrays that return to frame 0's values for a frame or two ("blip") are in the mix;
+    the file is the host path's all the same."""
+    _run(seed, tmp_path, exact=True)
+
+
+def _run(seed, tmp_path, exact):
     import pgsd.fl as fl
     import pgsd.hoomd as hoomd
-    rng = np.random.default_rng(9100 + seed)
+    rng = np.random.default_rng((9100 if not exact else 19100) + seed)
     n0 = int(rng.choice([1, 7, 300, 2000, 5000, 70_000]))
     nframes = int(rng.integers(2, 7))
     resize_at = int(rng.integers(1, nframes)) if rng.random() < 0.25 else None
     names = [nm for nm in SPEC if rng.random() < 0.7] or ["position"]
-    behaviour = {nm: rng.choice(["static", "moving", "once"]) for nm in names}
+    behaviour = {nm: rng.choice(["static", "moving", "once"] + (["blip"] if exact else [])) for nm in names}
     once_at = {nm: int(rng.integers(1, nframes)) for nm in names}
     on_gpu = {nm: bool(rng.random() < 0.7) for nm in names}
     # the frames, as host arrays
@@ -76,6 +87,8 @@ def test_random_trajectories_match_the_host_path(seed, tmp_path):
                 # path even if it returns to frame 0's values (the host path would elide it there) -- the one place
                 # where the two files may differ, exercised by tests/test_gpu_elision.py, kept out of this comparison
                 cur[nm] = _values(rng, nm, n) + SPEC[nm][0](10 * k)
+            elif b == "blip":                   # other values in ONE frame, frame 0's again afterwards
+                cur[nm] = _values(rng, nm, n) + SPEC[nm][0](700) if k == once_at[nm] else changed.get(nm, base[nm])
             else:
                 if k == once_at[nm]:
                     changed[nm] = _values(rng, nm, n) + SPEC[nm][0](500)
@@ -85,6 +98,8 @@ def test_random_trajectories_match_the_host_path(seed, tmp_path):
     keep = []
     for path, device in ((a, True), (b, False)):
         with hoomd.open(path, "w") as t:
+            if exact:
+                t.device_elision = 'exact'
             for k, (n, cur) in enumerate(frames):
                 fr = hoomd.Frame()
                 fr.configuration.step = k
@@ -95,4 +110,4 @@ def test_random_trajectories_match_the_host_path(seed, tmp_path):
             if device:
                 t.file.frame_sync()
     with open(a, "rb") as fa, open(b, "rb") as fb:
-        assert fa.read() == fb.read(), (seed, n0, nframes, resize_at, behaviour, on_gpu)
+        assert fa.read() == fb.read(), (seed, exact, n0, nframes, resize_at, behaviour, on_gpu)
