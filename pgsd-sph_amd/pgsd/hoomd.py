@@ -410,8 +410,9 @@ class HOOMDTrajectory(object):
           `_device_elision_votes`): packed by one launch, their packed bytes compared with this rank's rows of frame 0
           in device memory, the equal ones elided like host arrays -- byte equality, frame 0 itself always written
           in full (no default-value test), an array that differed once is written from then on without a comparison,
-          a change of the partition ends the comparisons.  ``device_elision = False``: always written, consecutive
-          device fields in one fused pack launch each;
+          a change of the partition ends the comparisons.  ``device_elision = 'exact'``: every array compared in
+          every frame (the host path's decisions); ``False``: always written, consecutive device fields in one fused
+          pack launch each;
         * upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom) follow the
           SPH set in that order when they are set.
         """
