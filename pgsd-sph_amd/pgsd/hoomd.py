@@ -31,8 +31,28 @@ from .version import __version__ as _pgsd_version
 logger = logging.getLogger('pgsd.hoomd')
 
 
+_HOST_TYPES = (numpy.ndarray, numpy.generic, int, float, list, tuple, str)
+
+
 def _is_device(x):
+    if isinstance(x, _HOST_TYPES):      # the common case first: no attribute lookups on the torch side
+        return False
     return fl is not None and (isinstance(x, fl.DeviceField) or fl._is_device_tensor(x))
+
+
+_SCHEMA_NAMES = []
+
+
+def _schema_names(frame):
+    """(path, chunk names in the order of the `_default_value` tables) of the three containers, built once."""
+    if not _SCHEMA_NAMES:
+        for path in ('configuration', 'particles', 'constraints'):
+            container = getattr(frame, path)
+            names = list(container._default_value)
+            if path == 'particles':
+                names += list(container._extra_default_value)
+            _SCHEMA_NAMES.append((path, tuple(names)))
+    return _SCHEMA_NAMES
 
 
 def _rows(x):
@@ -267,7 +287,10 @@ class _FrameSubset(object):
 def _equal(a, b):
     """`numpy.array_equal`, deciding from the first rows where it can: a 10^6-particle array that differs from
     frame 0 differs in its first rows, and comparing all of it costs as much as writing it."""
-    a, b = numpy.asarray(a), numpy.asarray(b)
+    if type(a) is not numpy.ndarray or type(b) is not numpy.ndarray:
+        if isinstance(a, (int, float, numpy.number)) and isinstance(b, (int, float, numpy.number)):
+            return bool(a == b)             # step, dimensions, N: no array is made of two scalars
+        a, b = numpy.asarray(a), numpy.asarray(b)
     if a.shape != b.shape:
         return False
     if a.ndim >= 1 and a.shape[0] > 4096 and not (a[:1024] == b[:1024]).all():
@@ -460,21 +483,22 @@ class HOOMDTrajectory(object):
         plan = []
         dev = []        # GPU-resident per-particle attributes: (index in plan, chunk name, DeviceField), schema order
         host_pp = []    # several ranks: per-particle HOST arrays that would be written: (index in plan, chunk name, array)
-        for path in ('configuration', 'particles', 'constraints'):
-            container = getattr(frame, path)
-            names = list(container._default_value)
-            if path == 'particles':
-                names += list(container._extra_default_value)
-            values = container.__dict__
+        at_count = None
+        for path, names in _schema_names(frame):
+            values = getattr(frame, path).__dict__
+            particles = path == 'particles'
             for name in names:
-                if (path, name) == ('particles', 'N'):
+                if particles and name == 'N':
                     # None = "as in frame 0": no count chunk; decided below from the global count otherwise
+                    at_count = len(plan)
                     plan.append((path, name, frame.particles.N is not None))
                     continue
-                value = values.get(name, values.get('_' + name))
+                value = values.get(name)
+                if value is None and name == 'box':
+                    value = values.get('_box')              # (the one attribute kept behind a property)
                 if value is None:
                     plan.append((path, name, False))        # most of the schema, most of the time: not set
-                elif path == 'particles' and _is_device(value) and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
+                elif particles and _is_device(value) and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
                     dt, _ = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
                     field = value if isinstance(value, fl.DeviceField) else fl.DeviceField.from_tensor(value, out_dtype=dt)
                     dev.append((len(plan), path + '/' + name, field))
@@ -504,8 +528,8 @@ class HOOMDTrajectory(object):
             agreed = allb[:, 8:].max(axis=0)
             plan = [(p, n, bool(a)) for (p, n, _), a in zip(plan, agreed)]
         n_global = int(part_dist.sum())
-        plan = [(p, n, self._should_write(p, n, frame, n_global) if (p, n) == ('particles', 'N') and w else w)
-                for p, n, w in plan]
+        if at_count is not None and plan[at_count][2]:
+            plan[at_count] = ('particles', 'N', self._should_write('particles', 'N', frame, n_global))
         self._elision_outcome(dev, host_pp, plan, compared, part0, part_dist)
         declared = size > 1 and hasattr(self.file, 'set_partition')
         if declared:
@@ -747,6 +771,11 @@ class HOOMDTrajectory(object):
             if initial_data is not None and _equal(initial_data, data):
                 logger.debug('skipping data chunk, matches frame 0: ' + path + '/' + name)
                 return False
+        # a value that matches the default is elided -- unless frame 0 holds the chunk (a reader would take frame 0's
+        # value for the default).  Most chunks that are written at all are in frame 0: the lookup comes first, the
+        # comparison with the default (the dearer of the two) only when it can decide something
+        if (path + '/' + name) in (self._frame0_chunks or ()):
+            return True
         default = container._default_value.get(name)
         if default is None and path == 'particles':
             default = container._extra_default_value.get(name)
@@ -754,7 +783,7 @@ class HOOMDTrajectory(object):
             matches_default_value = data == default
         else:
             matches_default_value = _equiv(data, default)
-        if matches_default_value and (path + '/' + name) not in (self._frame0_chunks or ()):
+        if matches_default_value:
             logger.debug('skipping data chunk, default value: ' + path + '/' + name)
             return False
         return True
