@@ -439,7 +439,9 @@ class HOOMDTrajectory(object):
         * upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom) follow the
           SPH set in that order when they are set.
         """
-        logger.debug('Appending frame to hoomd trajectory: ' + str(self.file))
+        debug = logger.isEnabledFor(logging.DEBUG)
+        if debug:
+            logger.debug('Appending frame to hoomd trajectory: ' + str(self.file))
         frame.validate()
         rank, size = self._comm()
 
@@ -548,7 +550,8 @@ class HOOMDTrajectory(object):
             container = getattr(frame, path)
             data = getattr(container, name)
             chunk = path + '/' + name
-            logger.debug('writing data chunk: ' + chunk)
+            if debug:
+                logger.debug('writing data chunk: ' + chunk)
             if path == 'particles' and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
                 dt, M = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
                 if at in dev_at:
@@ -853,7 +856,8 @@ class HOOMDTrajectory(object):
         from the default values, returned read-only (hoomd.py:724-902)."""
         if idx >= len(self):
             raise IndexError
-        logger.debug('reading frame ' + str(idx) + ' from: ' + str(self.file))
+        if logger.isEnabledFor(logging.DEBUG):
+            logger.debug('reading frame ' + str(idx) + ' from: ' + str(self.file))
         if self._initial_frame is None and idx != 0:
             self._read_frame(0)
 
