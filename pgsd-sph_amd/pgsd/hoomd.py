@@ -40,6 +40,21 @@ def _is_device(x):
     return fl is not None and (isinstance(x, fl.DeviceField) or fl._is_device_tensor(x))
 
 
+_READER_FIELDS = {}
+
+
+def _reader_fields(path, container):
+    """(name, default, chunk name, upstream-only attribute?) of the per-row chunks of a container, built once."""
+    fields = _READER_FIELDS.get(path)
+    if fields is None:
+        items = [(n, d, False) for n, d in container._default_value.items()]
+        if path == 'particles':
+            items += [(n, d, True) for n, d in container._extra_default_value.items()]
+        fields = tuple((n, d, path + '/' + n, opt) for n, d, opt in items if n not in ('N', 'types', 'type_shapes'))
+        _READER_FIELDS[path] = fields
+    return fields
+
+
 _SCHEMA_NAMES = []
 
 
@@ -371,6 +386,7 @@ class HOOMDTrajectory(object):
         self._dev_dynamic = set()      # GPU-resident chunks seen to differ from frame 0: not compared any more
         self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
         self._host_ref = {}            # several ranks: chunk -> this rank's rows of frame 0 (host arrays are compared too)
+        self._prefix_names = {}        # reader: prefix -> (nnames when asked, matching chunk names)
         self._frame0_dev_part = None   # read_frame_device: the partition whose rows of frame 0 are kept in HBM ...
         self._frame0_dev_cache = {}    # ... chunk -> GPU tensor
         logger.info('opening HOOMDTrajectory: ' + str(self.file))
@@ -842,6 +858,19 @@ class HOOMDTrajectory(object):
         warnings.warn("Deprecated, trajectory[idx]", DeprecationWarning)
         return self._read_frame(idx)
 
+    def _names_with_prefix(self, prefix):
+        """`find_matching_chunk_names(prefix)`, asked again only when the file's name list has grown (names are never
+        removed): the reader looks `log/` and `state/` up for every frame."""
+        f = self.file
+        n = getattr(f, 'nnames', None)
+        if n is None:                       # pgsd.pypgsd.PGSDFile: the pure-Python reader keeps no count
+            return f.find_matching_chunk_names(prefix, False)
+        cached = self._prefix_names.get(prefix)
+        if cached is None or cached[0] != n:
+            cached = (n, f.find_matching_chunk_names(prefix, False))
+            self._prefix_names[prefix] = cached
+        return cached[1]
+
     def _read_scalar(self, idx, chunk, container, attr, fallback_path):
         if self.file.chunk_exists(frame=idx, name=chunk, write_all=False):
             arr = self.file.read_chunk(frame=idx, name=chunk, offset=numpy.uint32(0), r_all=False)
@@ -904,14 +933,7 @@ class HOOMDTrajectory(object):
                 else:
                     container.type_shapes = container._default_value['type_shapes']
 
-            defaults = list(container._default_value.items())
-            optional = list(container._extra_default_value.items()) if path == 'particles' else []
-            optional_names = set(n for n, _ in optional)
-            for name, default in defaults + optional:
-                if name in ('N', 'types', 'type_shapes'):
-                    continue
-                chunk = path + '/' + name
-                is_optional = name in optional_names
+            for name, default, chunk, is_optional in _reader_fields(path, container):
                 if self.file.chunk_exists(frame=idx, name=chunk, write_all=False):
                     container.__dict__[name] = self.file.read_chunk(frame=idx, name=chunk, offset=numpy.uint32(0),
                                                                     r_all=False)
@@ -928,14 +950,14 @@ class HOOMDTrajectory(object):
                     container.__dict__[name][:] = tmp
                 container.__dict__[name].flags.writeable = False
 
-        for log in self.file.find_matching_chunk_names('log/', False):
+        for log in self._names_with_prefix('log/'):
             if self.file.chunk_exists(frame=idx, name=log, write_all=False):
                 snap.log[log[4:]] = self.file.read_chunk(frame=idx, name=log, offset=numpy.uint32(0), r_all=False)
             elif self._initial_frame is not None and log[4:] in self._initial_frame.log:
                 snap.log[log[4:]] = self._initial_frame.log[log[4:]]
 
         # state chunks belong to the frame they were written in (no fall-back, as upstream GSD reads them)
-        for state in self.file.find_matching_chunk_names('state/', False):
+        for state in self._names_with_prefix('state/'):
             if self.file.chunk_exists(frame=idx, name=state, write_all=False):
                 snap.state[state[6:]] = self.file.read_chunk(frame=idx, name=state, offset=numpy.uint32(0), r_all=False)
 
