@@ -1083,11 +1083,11 @@ class HOOMDTrajectory(object):
         f.wait_read()
         for name, chunk in fresh:
             cache[chunk] = getattr(snap.particles, name).clone()
-        for log in f.find_matching_chunk_names('log/', False):
+        for log in self._names_with_prefix('log/'):
             fr = frame_of(log)
             if fr is not None:
                 snap.log[log[4:]] = f.read_chunk(fr, log)
-        for state in f.find_matching_chunk_names('state/', False):
+        for state in self._names_with_prefix('state/'):
             if f.chunk_exists(idx, state):
                 snap.state[state[6:]] = f.read_chunk(idx, state)
         return snap
