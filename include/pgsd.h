@@ -438,8 +438,9 @@ extern "C"
        chunk order -- same arguments, same exchange, same placement as pgsd_write_chunks_device, minus the
        launch.  Chunks of a ticket that were never written are dropped by the next pgsd_end_frame / pgsd_close.
        (For a simulation that can stage right behind its last kernel and has other work before the frame is
-       sealed.  pgsd.hoomd does NOT use it: staging ahead of its schema bookkeeping was measured and bought
-       nothing -- the extra call cost what the hidden kernel wait saved) */
+       sealed, and for the elision test below, which needs the packed bytes before it is known what is written.
+       Staging merely to hide the kernel behind pgsd.hoomd's schema bookkeeping was measured and bought nothing --
+       the extra call cost what the hidden kernel wait saved) */
     int pgsd_stage_chunks_device(struct pgsd_handle* handle, uint32_t n_chunks, const struct pgsd_chunk_req* chunks,
                                  uint64_t N, uint64_t* ticket);
     int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
@@ -452,11 +453,11 @@ extern "C"
        ref[i] -- device memory holding the same rows of the other frame as the chunk stores them, N * M *
        sizeof(type) bytes (read with pgsd_read_chunk_device, or kept with pgsd_copy_staged_chunks) -- and sets
        equal[i] = 1 when every byte matches, 0 when not or when ref[i] is NULL (a rank without rows: 1).  One
-       kernel launch behind the pack -- and behind whatever the caller's source stream (pgsd_device_set_source_stream)
-       holds, like the pack itself: the references may have been written there a moment ago --, one stream wait;
-       local, no collective: the caller agrees the outcome over
-       the ranks like any other write / skip decision and then writes (pgsd_write_staged_chunks) or does not
-       (unwritten chunks are dropped by pgsd_end_frame).  Byte equality: NaNs with equal bits are equal, -0.0 and
+       kernel launch behind the pack -- and behind whatever the caller's source stream
+       (pgsd_device_set_source_stream) holds, like the pack itself: the references may have been written there a
+       moment ago --, one stream wait; local, no collective: the caller agrees the outcome over the ranks like any
+       other write / skip decision and then writes (pgsd_write_staged_chunks) or does not (unwritten chunks are
+       dropped by pgsd_end_frame).  Byte equality: NaNs with equal bits are equal, -0.0 and
        0.0 are not -- eliding is always safe, a reader gets the same bits back from frame 0.
        pgsd_copy_staged_chunks copies the packed bytes into caller-owned device memory dst[i] (NULL: skipped),
        asynchronously behind the pack: complete after pgsd_device_wait_packed, a comparison or pgsd_end_frame. */
