@@ -10,8 +10,12 @@
 //                           MPI_Allgather of benchmark-write.cc:39-45), placement, copies, writes, index
 // (pgsd_set_frame_exchange; pass "perchunk" as 4th argument for one exchange per chunk and the caller-side
 // pgsd_partition_rows instead; "declared": the row counts exchanged ONCE before the first frame are declared with
-// pgsd_set_partition and the frames then cost no collective at all) and prints MB/s the way the reference's
-// benchmark does, as one JSON line on rank 0.
+// pgsd_set_partition and the frames then cost no collective at all; "elide": declared, plus the elision test a
+// snapshot writer with static per-particle arrays would run -- every frame stages position, velocity, type id and a
+// charge that changes with the step, compares the packed chunks with frame 0's rows kept in HBM
+// (pgsd_copy_staged_chunks / pgsd_compare_staged_chunks), agrees the outcome over the ranks with one small
+// allgather and writes only what differs: after frame 0 that is the charge alone) and prints MB/s the way the
+// reference's benchmark does, as one JSON line on rank 0.
 // With "rccl" as 5th argument the ranks bootstrap the library's RCCL communicator themselves -- rank 0's
 // ncclUniqueId travels over the shm communicator they met on -- and every exchange of the run is an
 // ncclAllGather over xGMI: the path a C++ caller (HOOMD-SPH's dump writer) takes without MPI or torch.
@@ -19,7 +23,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -I include benchmark_write.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
 // With "keep" as 6th argument the file is left behind (benchmark_read.hip reads it back and checks the values).
 //
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk|declared] [shm|rccl] [keep]
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./benchmark_write [particles_per_rank] [frames] [file] [batched|perchunk|declared|elide] [shm|rccl] [keep]
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -42,6 +46,13 @@ __global__ void fill_scalar4(float4* pos, float4* vel, uint64_t n, uint64_t row0
     vel[i] = make_float4(0.001f * (float)(g % 77), 1.f, -1.f, 2.5f);             // w = mass
     }
 
+__global__ void fill_charge(float* charge, uint64_t n, uint64_t row0, uint64_t step)
+    {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        charge[i] = (float)((row0 + i) % 13) + 100.f * (float)step;
+    }
+
 #define CHECK(x)                                                                     \
     do                                                                               \
         {                                                                            \
@@ -58,7 +69,8 @@ int main(int argc, char** argv)
     const uint64_t n = argc > 1 ? strtoull(argv[1], NULL, 10) : 10000000ull;
     const int frames = argc > 2 ? atoi(argv[2]) : 10;
     const char* path = argc > 3 ? argv[3] : "/dev/shm/pgsd_benchmark_write.gsd";
-    const bool declared = argc > 4 && strcmp(argv[4], "declared") == 0;
+    const bool elide = argc > 4 && strcmp(argv[4], "elide") == 0;
+    const bool declared = elide || (argc > 4 && strcmp(argv[4], "declared") == 0);
     const bool batched = !declared && !(argc > 4 && strcmp(argv[4], "perchunk") == 0);
     const bool keep = argc > 6 && strcmp(argv[6], "keep") == 0;
     CHECK(pgsd_comm_init_from_env());
@@ -94,8 +106,18 @@ int main(int argc, char** argv)
 
     struct pgsd_handle h;
     CHECK(pgsd_create_and_open(&h, path, "benchmark_write", "hoomd", pgsd_make_version(1, 4), PGSD_OPEN_READWRITE, 0));
-    struct pgsd_chunk_req req[3];
+    float* charge = NULL;
+    if (elide)
+        (void)hipMalloc((void**)&charge, (n ? n : 1) * sizeof(float));
+    struct pgsd_chunk_req req[4];
     memset(req, 0, sizeof(req));
+    req[3].name = "particles/charge";
+    req[3].type = PGSD_TYPE_FLOAT;
+    req[3].M = 1;
+    req[3].src = {charge, NULL, PGSD_TYPE_FLOAT, 1, 0, 0};
+    void* frame0_rows[4] = {NULL, NULL, NULL, NULL}; // elide: frame 0's packed rows of this rank, kept in HBM
+    const size_t packed_bytes[4] = {(size_t)n * 12, (size_t)n * 12, (size_t)n * 4, (size_t)n * 4};
+    unsigned long long chunks_written = 0, chunks_elided = 0;
     req[0].name = "particles/position";
     req[0].type = PGSD_TYPE_FLOAT;
     req[0].M = 3;
@@ -117,7 +139,38 @@ int main(int argc, char** argv)
         if (!batched && !declared)
             CHECK(pgsd_partition_rows(n, &row0, &n_global, NULL));
         CHECK(pgsd_write_chunk(&h, "configuration/step", PGSD_TYPE_UINT64, 1, 1, 1, 1, 0, 1, false, 0, &step));
-        if (batched || declared)
+        if (elide)
+            {
+            hipLaunchKernelGGL(fill_charge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, charge, n, row0, step);
+            uint64_t ticket = 0;
+            uint8_t same[4] = {0, 0, 0, 0};
+            CHECK(pgsd_stage_chunks_device(&h, 4, req, n, &ticket)); // ONE fused pack launch for the four arrays
+            if (step == 0)
+                {
+                for (int i = 0; i < 4; i++)
+                    (void)hipMalloc(&frame0_rows[i], packed_bytes[i] ? packed_bytes[i] : 4);
+                CHECK(pgsd_copy_staged_chunks(&h, ticket, 0, 4, frame0_rows));
+                }
+            else
+                CHECK(pgsd_compare_staged_chunks(&h, ticket, 0, 4, frame0_rows, same));
+            // a chunk is skipped only when EVERY rank found its rows unchanged
+            std::vector<uint8_t> votes((size_t)P * 4);
+            CHECK(pgsd_comm_allgather(same, votes.data(), 4));
+            for (uint32_t i = 0; i < 4; i++)
+                {
+                bool skip = true;
+                for (int r = 0; r < P; r++)
+                    skip = skip && votes[(size_t)r * 4 + i] != 0;
+                if (skip)
+                    chunks_elided++;
+                else
+                    {
+                    CHECK(pgsd_write_staged_chunks(&h, ticket, i, 1, PGSD_PARTITION_AUTO, 0));
+                    chunks_written++;
+                    }
+                }
+            }
+        else if (batched || declared)
             CHECK(pgsd_write_chunks_device(&h, 3, req, n, PGSD_PARTITION_AUTO, 0));
         else
             CHECK(pgsd_write_chunks_device(&h, 3, req, n, n_global, row0));
@@ -141,15 +194,20 @@ int main(int argc, char** argv)
         {
         printf("{\"ranks\": %d, \"particles_per_rank\": %llu, \"frames\": %d, \"seconds\": %.4f, \"MBps\": %.1f, "
                "\"pack_launches\": %llu, \"written_bytes_rank0\": %llu, \"exchange\": \"%s\", "
-               "\"collectives_rank0\": %llu, \"comm\": \"%s\"}\n",
+               "\"collectives_rank0\": %llu, \"comm\": \"%s\", \"chunks_written\": %llu, \"chunks_elided\": %llu}\n",
                P, (unsigned long long)n, frames, dt, (double)frames * (double)n_global * 28.0 / dt / 1e6,
                (unsigned long long)st.pack_launches, (unsigned long long)st.written_bytes,
-               declared ? "none (declared partition)" : batched ? "one per frame" : "one per chunk", collectives, comm_name);
+               elide ? "none for the chunks (declared partition); one vote allgather per frame"
+               : declared ? "none (declared partition)" : batched ? "one per frame" : "one per chunk",
+               collectives, comm_name, chunks_written, chunks_elided);
         if (!keep)
             unlink(path);
         }
     pgsd_comm_finalize();
     (void)hipFree(pos);
     (void)hipFree(vel);
+    (void)hipFree(charge);
+    for (int i = 0; i < 4; i++)
+        (void)hipFree(frame0_rows[i]);
     return 0;
     }

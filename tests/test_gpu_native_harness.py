@@ -101,3 +101,28 @@ def test_declared_partition_harness_writes_without_a_collective_per_frame(tmp_pa
     r = _run_ranks(READ_EXE, [path, "verify"], 2)
     assert r["verified"] is True and r["mismatches"] == 0 and r["particles"] == per_rank * writers
     assert r["frames"] == frames + 1
+
+
+@pytest.mark.parametrize("writers", [1, 2])
+def test_elide_harness_writes_only_what_differs_from_frame_0(tmp_path, writers):
+    """`benchmark_write ... elide`: pgsd_stage_chunks_device + pgsd_copy_staged_chunks / pgsd_compare_staged_chunks +
+    pgsd_write_staged_chunks from C++ alone (no Python in the data path): position, velocity and type id never
+    change and are written in frame 0 only, the charge changes with the step and is written every frame."""
+    import numpy as np
+    import pgsd.fl as fl
+    product.build()
+    path = str(tmp_path / "elide.gsd")
+    per_rank, frames = 60007, 4
+    d = _run_ranks(EXE, [per_rank, frames, path, "elide", "shm", "keep"], writers)
+    assert d["ranks"] == writers and d["chunks_written"] == 4 + frames and d["chunks_elided"] == 3 * frames, d
+    assert d["pack_launches"] == frames + 1
+    n_global = per_rank * writers
+    with fl.open(path, "r") as f:
+        assert f.nframes == frames + 1
+        for k in range(frames + 1):
+            assert f.chunk_exists(k, "particles/charge")
+            assert f.chunk_exists(k, "particles/position") == (k == 0) == f.chunk_exists(k, "particles/typeid")
+            want = (np.arange(n_global, dtype=np.uint64) % 13).astype(np.float32) + np.float32(100.0 * k)
+            assert f.read_chunk(k, "particles/charge").tobytes() == want.tobytes()
+    r = _run_ranks(READ_EXE, [path, "verify"], 3)         # frame 0 holds the arrays the read harness verifies
+    assert r["verified"] is True and r["mismatches"] == 0 and r["rows_read"] == n_global
