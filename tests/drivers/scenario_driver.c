@@ -470,6 +470,12 @@ int main(int argc, char** argv)
                 g_defer = 0;
 #endif
             }
+        else if (strcmp(cmd, "localreads") == 0 && nt == 2)
+            {
+#ifndef PGSD_DRIVER_REF
+            rc = pgsd_set_local_reads(&handle, atoi(tok[1])); /* reads that take no part in a collective flush */
+#endif
+            }
         else if (strcmp(cmd, "dump") == 0)
             {
 #ifndef PGSD_DRIVER_REF

@@ -79,3 +79,19 @@ def batched_script(path, out_path, mode=1):
     with open(out_path, "w") as f:
         f.writelines(lines)
     return out_path
+
+
+def local_reads_script(path, out_path):
+    """The same scenario with pgsd_set_local_reads(1) on every handle (`localreads 1` behind create / open)."""
+    lines = []
+    with open(path) as f:
+        for line in f:
+            tok = line.split("#", 1)[0].split()
+            if tok and tok[0] == "prefill" and not os.path.isabs(tok[1]):   # looked up beside the ORIGINAL script
+                line = "prefill %s\n" % os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(path)), "..", "files", tok[1]))
+            lines.append(line)
+            if tok and tok[0] in ("create", "open"):
+                lines.append("localreads 1\n")
+    with open(out_path, "w") as f:
+        f.writelines(lines)
+    return out_path

@@ -79,3 +79,18 @@ def test_product_under_mpiexec_matches_reference_file(mpi_driver, name, P, tmp_g
     with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
         assert f.read() == g.read()
     assert [ln for ln in out.stdout.decode().splitlines() if ln.strip()] == S.read_log(golden[:-4] + ".log")
+
+
+@pytest.mark.parametrize("name", ["readback", "idxbuf", "vone_append"])
+def test_local_reads_on_one_rank_change_nothing(name, tmp_gsd, tmp_path):
+    """pgsd_set_local_reads(1): a read drains this rank's own copies instead of running the reference's collective
+    flush (pgsd.c:2436-2537).  On one rank -- every row is this rank's -- the reads of the goldens that read return
+    the same bytes and the file stays the reference's."""
+    import re
+    scn = product.local_reads_script(S.scenario_path(name), str(tmp_path / "local.scn"))
+    golden = os.path.join(S.GOLDEN, "%s.p1.gsd" % name)
+    log = product.run_driver(scn, tmp_gsd, 1, allow_fail=_fails_on_purpose(golden))
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        assert f.read() == g.read()
+    strip = lambda ls: [re.sub(r"line=\d+ ", "", ln) for ln in ls if "cmd=localreads" not in ln]
+    assert strip(log) == strip(S.read_log(golden[:-4] + ".log"))

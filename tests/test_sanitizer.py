@@ -54,6 +54,19 @@ def test_scenarios_are_sanitizer_clean(asan_driver, name, P, batched, tmp_path):
         assert a.read() == b.read()
 
 
+def test_local_reads_are_sanitizer_clean(asan_driver, tmp_path):
+    """pgsd_set_local_reads(1) under ASan + UBSan: the read-heavy golden on one rank, file == the reference's."""
+    out = str(tmp_path / "out.gsd")
+    script = product.local_reads_script(S.scenario_path("readback"), str(tmp_path / "local.scn"))
+    env = dict(os.environ, PGSD_RANK="0", PGSD_NRANKS="1",
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([asan_driver, script, out], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180)
+    err = p.stderr.decode()
+    assert p.returncode == 0 and "ERROR" not in err and "runtime error" not in err, err[-2000:]
+    with open(out, "rb") as a, open(os.path.join(S.GOLDEN, "readback.p1.gsd"), "rb") as b:
+        assert a.read() == b.read()
+
+
 TSAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_tsan")
 
 BIG_CHUNKS = """create app hoomd 1 4 rw 0
