@@ -584,3 +584,19 @@ def test_exact_mode_elides_an_array_that_returns_to_frame_0(tmp_path):
         assert fa.read() == fb.read()
     with hoomd.open(a, "r") as t:
         assert [t.file.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, False, False]
+
+
+def test_device_reader_without_default_rows(tmp_path):
+    """`read_frame_device(defaults=False)`: attributes the file does not hold stay None instead of default rows."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(3), 800, 2)
+    path, keep = str(tmp_path / "t.gsd"), []
+    with hoomd.open(path, "w") as t:
+        for args in frames:
+            t.append(_frame(hoomd, fl, *args, True, keep))
+    with hoomd.open(path, "r") as t:
+        a, b = t.read_frame_device(1), t.read_frame_device(1, defaults=False)
+        assert a.particles.body is not None and int(a.particles.body[0]) == -1 and b.particles.body is None
+        assert b.particles.image is None and b.particles.mass.cpu().numpy().tobytes() == frames[0][3].tobytes()
+        assert b.particles.position.cpu().numpy().tobytes() == frames[1][1].tobytes()
