@@ -1038,6 +1038,7 @@ class HOOMDTrajectory(object):
         cache, fresh = self._frame0_dev_cache, []
         n_frame0 = None          # frame 0's arrays stand in only while the particle count is frame 0's (hoomd.py:858-884)
         default_rows = None      # this read's own copy of the default rows (one small device-to-device copy, below)
+        typed = {}
         for name, (dt, M) in specs:
             chunk = 'particles/' + name
             fr = frame_of(chunk)
@@ -1067,8 +1068,11 @@ class HOOMDTrajectory(object):
                 if default_rows is None:
                     default_rows = self._default_rows_template().clone()
                 off, words, tdt = self._default_rows_layout[name]
-                row = default_rows[off:off + words].view(tdt)
-                setattr(snap.particles, name, row.expand(n, M) if M > 1 else row.expand(n))
+                base = typed.get(tdt)
+                if base is None:
+                    base = typed[tdt] = default_rows.view(tdt)      # one re-typed view of the copy per element type
+                # one strided view per attribute: n rows that are all the same `words` elements (stride 0)
+                setattr(snap.particles, name, base.as_strided((n, M) if M > 1 else (n,), (0, 1) if M > 1 else (0,), off))
         if scalar4 and n >= 0:
             # HOOMD's Scalar4 arrays, every row stored WHOLE by the unpack launch: the columns a missing chunk
             # would have fed come from the `fill` of the chunk that is there (type id 0 as bits, mass 1.0,
