@@ -560,10 +560,9 @@ class HOOMDTrajectory(object):
         # 2. write, in the reference's chunk order; device fields go out in one fused launch
         device_fields = []      # not staged: consecutive GPU-resident fields leave in one fused launch
         staged_run = []         # staged (one launch for the whole frame, above): consecutive chunk numbers of the ticket
-        dev_at = dict((at, (k, field)) for k, (at, _, field) in enumerate(dev))
-        for at, (path, name, write) in enumerate(plan):
-            if not write:
-                continue
+        dev_at = dict((at, (k, field)) for k, (at, _, field) in enumerate(dev)) if dev else {}
+        for at in [i for i, entry in enumerate(plan) if entry[2]]:
+            path, name, _ = plan[at]
             container = getattr(frame, path)
             data = getattr(container, name)
             chunk = path + '/' + name
@@ -585,12 +584,16 @@ class HOOMDTrajectory(object):
                     default = container._default_value.get(name, container._extra_default_value.get(name))
                     data = numpy.empty([n_local] + ([M] if M > 1 else []), dtype=dt)
                     data[...] = default
-                self._flush_device_fields(device_fields, particle_offset, rank)
-                self._flush_staged(ticket, staged_run, particle_offset, rank)
+                if device_fields:
+                    self._flush_device_fields(device_fields, particle_offset, rank)
+                if staged_run:
+                    self._flush_staged(ticket, staged_run, particle_offset, rank)
                 self.file.write_chunk(chunk, data, particle_offset, rank, True)
                 continue
-            self._flush_device_fields(device_fields, particle_offset, rank)
-            self._flush_staged(ticket, staged_run, particle_offset, rank)
+            if device_fields:
+                self._flush_device_fields(device_fields, particle_offset, rank)
+            if staged_run:
+                self._flush_staged(ticket, staged_run, particle_offset, rank)
             # replicated small chunks (hoomd.py:604-630)
             if name == 'N':
                 count = n_global if path == 'particles' else int(container.N)
