@@ -67,3 +67,40 @@ def test_eight_ranks_uneven_partition_matches_the_oracle(kind, tmp_path):
     _oracle_frames(ref, P, frames)
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
+
+
+FULL = os.path.join(ROOT, "tests", "fullsize_ranks_worker.py")
+
+
+@pytest.mark.parametrize("kind", ["shm", "rccl"])
+@pytest.mark.parametrize("what", ["config3", "config4"])
+def test_eight_ranks_at_ten_million_particles_each_match_the_oracle(what, kind):
+    """BASELINE configs 3 and 4 at their own size AND rank count: eight ranks (threads) x 10 M particles, eight
+    pipelines and eight pinned rings onto one inode.  config3: position + velocity + typeid, two frames = 4.48 GB, the
+    second frame beyond 4 GiB of file offset; config4: the 112 B/particle SPH set, one frame = 8.96 GB.  sha256 of
+    the file == sha256 of the oracle's 8-rank file of host copies of the same values (every rank's rows at
+    file_size + offset * sz, pgsd.c:2225-2249; the partition of benchmark-write.cc:33-45)."""
+    import shutil
+    P, n = 8, 10_000_000
+    d = "/dev/shm"
+    need = 20 << 30                                  # the product's file and the oracle's side by side: 2 x 8.96 GB
+    if not os.path.isdir(d) or shutil.disk_usage(d).free < need:
+        pytest.skip("/dev/shm has less than 20 GB free")
+    env = dict(os.environ)
+    env.pop("PGSD_RCCL_LIBRARY", None)
+    if kind == "rccl":
+        product.build()
+        assert os.path.exists(FAKE)
+        env["PGSD_RCCL_LIBRARY"] = FAKE
+    p = subprocess.run([sys.executable, FULL, kind, str(P), str(n), what, d], env=env, capture_output=True, text=True,
+                       timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")]
+    assert lines, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+    r = dict(kv.split("=") for kv in lines[-1].split()[1:])
+    payload = P * n * (28 * 2 if what == "config3" else 112)
+    assert int(r["size_mine"]) == int(r["size_ref"]) > payload
+    if what == "config3":
+        assert int(r["size_mine"]) > (1 << 32) > int(r["size_mine"]) // 2        # frame 2 straddles the 4 GiB line
+    assert r["sha_mine"] == r["sha_ref"]
+    assert [float(v) for v in r["collectives"].split(",")] == [1.0] * P          # ONE collective per frame, every rank
+    assert p.returncode == 0, p.stderr[-3000:]
