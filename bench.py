@@ -223,6 +223,24 @@ def probe_rccl_exchange(device, n=300, nbytes=512):
         return None
 
 
+def fstype_of(path):
+    """File system type of the mount `path` lives on (/proc/mounts, longest mount point that is a prefix)."""
+    try:
+        real = os.path.realpath(path)
+        best, kind = "", None
+        with open("/proc/mounts") as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) < 3:
+                    continue
+                mp = parts[1].replace("\\040", " ")
+                if (real == mp or real.startswith(mp.rstrip("/") + "/")) and len(mp) >= len(best):
+                    best, kind = mp, parts[2]
+        return kind
+    except OSError:
+        return None
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched N-rank run: start N children of this script with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set (what torch.distributed.run would export), pass rank 0's stdout through and
@@ -235,7 +253,7 @@ def launch_ranks(n, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     import signal
@@ -278,6 +296,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", type=int, default=10_000_000, help="particles per GPU")
     ap.add_argument("--dir", default=os.environ.get("PGSD_BENCH_DIR", "/dev/shm"))
+    ap.add_argument("--dir-fallback", action="store_true",
+                    help="when --dir lacks room for the run, write to /tmp or the working directory instead of stopping "
+                         "(the file system then differs from run to run: config.target_fstype says which it was)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stall-test", action="store_true", help="skip the asynchronous-sealing stall measurement")
     ap.add_argument("--no-exchange-probe", action="store_true",
@@ -321,6 +342,13 @@ def main():
         if world != args.gpus:
             raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: the two must agree "
                              "(the JSON's n_gpus is the number of ranks that ran)" % (world, args.gpus))
+
+    # RCCL's intra-node transport shares device buffers between the rank processes by IPC handle, and the hosts
+    # of this pool only support dmabuf handles: with the legacy mode hipIpcGetMemHandle fails with "invalid
+    # argument" and ncclCommInitRank with it.  The image exports the setting already; a rank gets it here too when a
+    # launcher scrubbed the environment -- the same way whether torch.distributed.run or this script started the
+    # ranks, and before anything loads HIP.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner at
     # ncclCommInitRank, for one): from here on file descriptor 1 IS stderr, and the line goes out through a
@@ -427,31 +455,35 @@ def main():
 
     # The run appends world x (warmup + steps [+ 3 stall-test frames]) frames to ONE file: 2.24 GB per frame at eight
     # ranks.  A target without that much room would end the run in ENOSPC half-way (a tmpfs is also memory of the
-    # job): rank 0 looks first and, when --dir is too small, takes the first of /tmp and the working directory that
-    # is not -- the workload string names the directory that was used.
-    need = world * (args.warmup + args.steps + 4) * N * payload_bpp + (256 << 20)
-    choice = [args.dir]
+    # job): rank 0 looks first.  When --dir is too small the run STOPS with the figures -- a 1 -> 8 curve whose points
+    # landed on different file systems (tmpfs 7 GB/s, page cache 11 GB/s) would not be a curve -- unless
+    # --dir-fallback allows the first of /tmp and the working directory that has the room.  Either way the JSON names
+    # the directory and its file system type (config.target_dir / config.target_fstype).
+    extra = 4 if world == 1 and not args.no_stall_test else 1
+    need = world * (args.warmup + args.steps + extra) * N * payload_bpp + (256 << 20)
+    choice = [None]
     if rank == 0:
         import shutil
-        for cand in (args.dir, "/tmp", os.getcwd()):
+        for cand in ((args.dir, "/tmp", os.getcwd()) if args.dir_fallback else (args.dir,)):
             try:
                 if shutil.disk_usage(cand).free >= need * 1.05 and os.access(cand, os.W_OK):
                     choice = [cand]
                     break
             except OSError:
                 continue
-        else:
-            choice = [None]
     if world > 1:
         dist.broadcast_object_list(choice, src=0)
     if choice[0] is None:
-        raise SystemExit("bench.py: the run writes %.1f GB (%d ranks x %d frames x %.2f GB) and neither %s, /tmp nor the "
-                         "working directory has that much room: fewer --steps, or --dir <larger target>"
-                         % (need / 1e9, world, args.warmup + args.steps + 4, N * payload_bpp / 1e9, args.dir))
+        raise SystemExit("bench.py: the run writes %.1f GB (%d ranks x %d frames x %.2f GB) and %s has not that much room%s: "
+                         "fewer --steps, --dir <larger target>, or --dir-fallback to let the run move to /tmp or the "
+                         "working directory"
+                         % (need / 1e9, world, args.warmup + args.steps + extra, N * payload_bpp / 1e9, args.dir,
+                            " (nor /tmp, nor the working directory)" if args.dir_fallback else ""))
     if choice[0] != args.dir:
-        print("bench.py: %s has less than the %.1f GB the run writes: writing to %s instead"
+        print("bench.py: %s has less than the %.1f GB the run writes: writing to %s instead (--dir-fallback)"
               % (args.dir, need / 1e9, choice[0]), file=sys.stderr)
         args.dir = choice[0]
+    target_fstype = fstype_of(args.dir)
     path = os.path.join(args.dir, "pgsd_bench_%s.gsd" % os.environ.get("MASTER_PORT", str(os.getpid())))
     f = fl.open(path, "w", application="pgsd_amd bench", schema="hoomd", schema_version=[1, 4])
     f.configure_device(device=local_rank, slab_bytes=args.slab_mib << 20, n_slabs=args.slabs,
@@ -584,7 +616,7 @@ def main():
                                       "sph": "the 14 per-particle chunks of the PGSD-SPH schema (112 B/particle)",
                                       "union": "the 19 per-particle chunks of the SPH schema + upstream HOOMD attributes "
                                                "(164 B/particle)"}[args.schema], layout, comm_backend, args.dir),
-                   "schema": args.schema,
+                   "schema": args.schema, "target_dir": args.dir, "target_fstype": target_fstype,
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
         "comm_backend": comm_backend,

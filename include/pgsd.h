@@ -253,7 +253,10 @@ extern "C"
        be in the file: its own rows of a sealed frame, or any rows of a file that was opened after they were
        written.  (pgsd.hoomd reads each rank's rows of frame 0 this way when it first compares an array with them;
        which arrays a rank compares need not be the same on every rank.)  Chunks of the open frame are not flushed
-       by a local read. */
+       by a local read.  The lookup in front of the read (pgsd_find_chunk, pgsd_find_matching_chunk_name) is local
+       too while this is on and there are several ranks: it sees what the last flush committed -- a frame that held
+       buffered small chunks only is not flushed by pgsd_end_frame (pgsd.c:1941-1950), and its chunks are not found
+       by a local lookup until the next collective flush. */
     int pgsd_set_local_reads(struct pgsd_handle* handle, int on);
     /* Perform the exchange now (collective; nothing is flushed): afterwards the queue is empty and the
        handle's mirror is current.  No-op when nothing is queued. */
@@ -343,6 +346,13 @@ extern "C"
        as ncclAllGather on device buffers on a private HIP stream. */
     int pgsd_comm_rccl_unique_id(void* unique_id_128);
     int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device);
+    /* What one rank can know BEFORE the collective bootstrap above: librccl loads with the entry points used and
+       `device` (-1: the current one) exists.  Callers let the ranks agree on it first, so that nobody waits inside
+       ncclCommInitRank for a rank that could never have come.  An exchange on an RCCL communicator waits at most
+       PGSD_COMM_TIMEOUT_S seconds (environment, default 120) for the other ranks; then -- or when RCCL reports an
+       asynchronous error -- the communicator is aborted (ncclCommAbort), the call returns PGSD_ERROR_COMM and so
+       does every later collective on it. */
+    int pgsd_comm_rccl_available(int device);
     int pgsd_comm_finalize(void);
     int pgsd_comm_rank(void);
     int pgsd_comm_size(void);
@@ -593,6 +603,13 @@ extern "C"
 
     /* 1 when a gfx950-capable HIP device is visible to this process */
     int pgsd_device_available(void);
+
+    /* A closed handle of the default pipeline geometry PARKS what is dear to make -- two streams, up to four 16 MiB
+       pinned slabs, the pinned arena of the small-frame path, up to four 256 MiB staging arenas in HBM (1 GiB), idle
+       events -- for the next handle on the same device: at most two sets per process, held until the process ends
+       (PGSD_NO_PARKING in the environment: nothing is parked).  This call gives every parked set back to the runtime
+       now; returns the number of sets freed.  Not to be called while another thread opens or closes a handle. */
+    int pgsd_device_release_parked(void);
 
 #ifdef __cplusplus
     }

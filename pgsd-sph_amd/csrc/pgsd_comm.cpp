@@ -28,10 +28,17 @@
 namespace pgsd_amd
     {
 static thread_local std::string g_last_error;
+static thread_local uint64_t g_last_error_serial = 0;
 
 void set_last_error(const std::string& s)
     {
     g_last_error = s;
+    g_last_error_serial++;
+    }
+
+uint64_t last_error_serial()
+    {
+    return g_last_error_serial;
     }
 
 const char* last_error()

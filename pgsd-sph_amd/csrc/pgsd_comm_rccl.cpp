@@ -15,13 +15,24 @@
 //
 // librccl is opened at run time (dlopen) so that libpgsd_amd.so has no hard dependency on
 // it: inside a PyTorch process the already-loaded RCCL (backend "nccl") is reused.
+//
+// Failure handling.  A peer that never enters the collective leaves RCCL's kernel spinning on the stream for good
+// (MPI_Allgather in the reference waits for ever as well, pgsd.c:1126); here the wait is BOUNDED: the host polls an
+// event recorded behind the device->host copy (hipEventQuery) against a deadline -- PGSD_COMM_TIMEOUT_S seconds,
+// default 120 -- and polls ncclCommGetAsyncError beside it.  On either the communicator is aborted
+// (ncclCommAbort: RCCL's kernels leave the stream), the call returns -1 (PGSD_ERROR_COMM at the C ABI) and the
+// context stays broken: every later collective on it fails at once.  The process is never re-executed.
 #include "pgsd_internal.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <sched.h>
+#include <unistd.h>
 
 namespace pgsd_amd
     {
@@ -33,6 +44,8 @@ struct RcclApi
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr; // optional: polled while waiting
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                        // optional: what ends a wait that timed out
     };
 
 static RcclApi g_rccl;
@@ -71,6 +84,8 @@ static bool load_rccl()
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    g_rccl.CommGetAsyncError = (decltype(g_rccl.CommGetAsyncError))dlsym(lib, "ncclCommGetAsyncError");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(lib, "ncclCommAbort");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
         {
         set_last_error("librccl lacks the expected nccl* symbols");
@@ -90,7 +105,86 @@ struct RcclCtx
     char* h_send = nullptr; // pinned
     char* h_recv = nullptr; // pinned
     size_t cap = 0;         // bytes per rank the buffers hold
+    hipEvent_t done = nullptr; // recorded behind the device->host copy of an exchange: what the host polls
+    double timeout_s = 120.0;  // PGSD_COMM_TIMEOUT_S
+    bool broken = false;       // a collective timed out / failed: aborted, every later call fails at once
+    bool stuck = false;        // the stream did not drain after the abort: its resources are left alone
+    std::string why;           // the first failure, repeated by the later calls
     };
+
+static const char* nccl_text(ncclResult_t r)
+    {
+    return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error";
+    }
+
+static double seconds_since(std::chrono::steady_clock::time_point t0)
+    {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+// The communicator is given up: RCCL's kernels are told to leave (ncclCommAbort also frees the communicator),
+// the stream gets a few seconds to drain what is left on it.
+static int rccl_break(RcclCtx* c, const std::string& why)
+    {
+    c->broken = true;
+    c->why = why;
+    if (c->comm && g_rccl.CommAbort)
+        (void)g_rccl.CommAbort(c->comm);
+    if (c->comm && !g_rccl.CommAbort)
+        c->stuck = true; // nothing can make the kernel leave: neither the communicator nor the stream is touched again
+    c->comm = g_rccl.CommAbort ? nullptr : c->comm;
+    if (!c->stuck && c->done)
+        {
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipEventQuery(c->done)) == hipErrorNotReady && seconds_since(t0) < 5.0)
+            usleep(1000);
+        if (q != hipSuccess)
+            c->stuck = true;
+        }
+    set_last_error(why);
+    return -1;
+    }
+
+// Wait for the exchange enqueued on the private stream, but not for ever: poll the event behind the last copy
+// (spinning at first -- an exchange among ranks that are all there takes ~17 us --, then yielding, then sleeping),
+// the communicator's asynchronous error beside it, and give up at the deadline.
+static int rccl_wait_bounded(RcclCtx* c)
+    {
+    const auto t0 = std::chrono::steady_clock::now();
+    double next_async_check = 1e-3;
+    for (;;)
+        {
+        const hipError_t q = hipEventQuery(c->done);
+        if (q == hipSuccess)
+            return 0;
+        if (q != hipErrorNotReady)
+            return rccl_break(c, std::string("RCCL exchange: the stream reports ") + hipGetErrorString(q));
+        const double el = seconds_since(t0);
+        if (el >= next_async_check)
+            {
+            next_async_check = el < 0.05 ? el + 1e-3 : el + 0.05;
+            ncclResult_t state = ncclSuccess;
+            if (g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(c->comm, &state) == ncclSuccess && state != ncclSuccess
+                && state != ncclInProgress)
+                return rccl_break(c, std::string("RCCL exchange failed asynchronously: ") + nccl_text(state));
+            if (el > c->timeout_s)
+                {
+                char msg[200];
+                snprintf(msg, sizeof(msg),
+                         "RCCL exchange timed out after %.1f s (PGSD_COMM_TIMEOUT_S): a rank did not arrive; "
+                         "communicator aborted", el);
+                return rccl_break(c, msg);
+                }
+            }
+        if (el < 200e-6)
+            __builtin_ia32_pause();
+        else if (el < 5e-3)
+            sched_yield();
+        else
+            usleep(200);
+        }
+    }
 
 static bool rccl_reserve(RcclCtx* c, size_t bytes)
     {
@@ -123,22 +217,25 @@ static bool rccl_reserve(RcclCtx* c, size_t bytes)
 static int rccl_allgather(void* p, const void* send, void* recv, size_t bytes)
     {
     RcclCtx* c = (RcclCtx*)p;
+    if (c->broken)
+        {
+        set_last_error("the RCCL communicator is broken: " + c->why);
+        return -1;
+        }
     if (bytes == 0)
         return 0;
     if (hipSetDevice(c->device) != hipSuccess || !rccl_reserve(c, bytes))
         return -1;
     memcpy(c->h_send, send, bytes);
     if (hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        return -1;
+        return rccl_break(c, "RCCL exchange: host->device copy failed");
     ncclResult_t r = g_rccl.AllGather(c->d_send, c->d_recv, bytes, ncclUint8, c->comm, c->stream);
     if (r != ncclSuccess)
-        {
-        set_last_error(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
-        return -1;
-        }
-    if (hipMemcpyAsync(c->h_recv, c->d_recv, bytes * (size_t)c->size, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        return -1;
-    if (hipStreamSynchronize(c->stream) != hipSuccess)
+        return rccl_break(c, std::string("ncclAllGather: ") + nccl_text(r));
+    if (hipMemcpyAsync(c->h_recv, c->d_recv, bytes * (size_t)c->size, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+        || hipEventRecord(c->done, c->stream) != hipSuccess)
+        return rccl_break(c, "RCCL exchange: device->host copy failed");
+    if (rccl_wait_bounded(c) != 0)
         return -1;
     memcpy(recv, c->h_recv, bytes * (size_t)c->size);
     return 0;
@@ -148,8 +245,17 @@ static void rccl_destroy(void* p)
     {
     RcclCtx* c = (RcclCtx*)p;
     (void)hipSetDevice(c->device);
+    if (c->stuck)
+        {
+        // a collective is still on the stream and nothing made it leave: the buffers it may touch, the stream and the
+        // communicator are left to the end of the process rather than freed under it
+        delete c;
+        return;
+        }
     if (c->comm)
         g_rccl.CommDestroy(c->comm);
+    if (c->done)
+        (void)hipEventDestroy(c->done);
     if (c->d_send)
         (void)hipFree(c->d_send);
     if (c->d_recv)
@@ -189,6 +295,32 @@ catch (...)
     }
 
 static int rccl_open_comm(const void* unique_id_128, int rank, int size, int device, pgsd_comm* out);
+
+// What a rank can know by itself before it enters ncclCommInitRank (which waits for every rank): librccl loads with
+// the entry points used here and the device can be selected.  The ranks agree on this first (pgsd.dist,
+// benchmark_write.hip), so that no rank waits inside the bootstrap for one that could never have come.
+extern "C" int pgsd_comm_rccl_available(int device)
+    try
+    {
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_comm_rccl_available: no HIP device visible");
+        return PGSD_ERROR_NO_DEVICE;
+        }
+    if (!load_rccl())
+        return PGSD_ERROR_COMM;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || (device >= 0 && device >= n))
+        {
+        set_last_error("pgsd_comm_rccl_available: device " + std::to_string(device) + " of " + std::to_string(n));
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
 
 extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device)
     try
@@ -233,7 +365,14 @@ static int rccl_open_comm(const void* unique_id_128, int rank, int size, int dev
     c->device = device;
     ncclUniqueId id;
     memcpy(&id, unique_id_128, sizeof(id));
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+    if (const char* t = getenv("PGSD_COMM_TIMEOUT_S"))
+        {
+        const double v = atof(t);
+        if (v > 0)
+            c->timeout_s = v;
+        }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+        || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
         {
         set_last_error("pgsd_comm_init_rccl: cannot select device / create stream");
         delete c;
@@ -242,7 +381,8 @@ static int rccl_open_comm(const void* unique_id_128, int rank, int size, int dev
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, size, id, rank);
     if (r != ncclSuccess)
         {
-        set_last_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+        set_last_error(std::string("ncclCommInitRank: ") + nccl_text(r));
+        c->comm = nullptr;
         rccl_destroy(c);
         return PGSD_ERROR_COMM;
         }

@@ -215,6 +215,47 @@ static std::vector<ParkedResources>& parked()
     return *v;
     }
 
+// Everything a parked set holds goes back to the runtime (pgsd_device_release_parked).
+static void free_parked(ParkedResources& r)
+    {
+    (void)hipSetDevice(r.device);
+    for (auto& sl : r.slabs)
+        {
+        if (sl.second)
+            (void)hipEventDestroy(sl.second);
+        if (sl.first)
+            (void)hipHostFree(sl.first);
+        }
+    if (r.dhost)
+        (void)hipHostFree(r.dhost);
+    for (char* a : r.arenas)
+        (void)hipFree(a);
+    for (hipEvent_t e : r.ev_plain)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_timing)
+        (void)hipEventDestroy(e);
+    if (r.pack_stream)
+        (void)hipStreamDestroy(r.pack_stream);
+    if (r.copy_stream)
+        (void)hipStreamDestroy(r.copy_stream);
+    }
+
+int release_parked_sets()
+    {
+    std::vector<ParkedResources> sets;
+        {
+        std::lock_guard<std::mutex> g(parked_mutex());
+        sets.swap(parked());
+        }
+    int device = 0;
+    const bool have = hipGetDevice(&device) == hipSuccess;
+    for (auto& r : sets)
+        free_parked(r);
+    if (have && !sets.empty())
+        (void)hipSetDevice(device);
+    return (int)sets.size();
+    }
+
 class DevicePipeline
     {
     public:
@@ -403,11 +444,11 @@ class DevicePipeline
         ParkedResources r;
         r.device = m_cfg.device;
         r.slab_bytes = m_cfg.slab_bytes;
-            {
-            std::lock_guard<std::mutex> g(parked_mutex());
-            if (parked().size() >= 2)
-                return false;
-            }
+        // room is checked and the set pushed under ONE lock (two pipelines closing at once could both see
+        // "one set parked" and leave three)
+        std::lock_guard<std::mutex> g(parked_mutex());
+        if (parked().size() >= 2)
+            return false;
         r.pack_stream = m_pack_stream;
         r.copy_stream = m_copy_stream;
         for (auto& sl : m_slabs)
@@ -434,7 +475,6 @@ class DevicePipeline
             }
         r.ev_plain = std::move(m_pool_plain);
         r.ev_timing = std::move(m_pool_timing);
-        std::lock_guard<std::mutex> g(parked_mutex());
         parked().push_back(std::move(r));
         return true;
         }
@@ -738,6 +778,12 @@ class DevicePipeline
                 src[i] = {c.job.dst, (size_t)(c.N * c.job.M * sizeof_type(c.job.dst_type))};
                 }
             }
+        // the destinations are the caller's memory (torch's caching allocator hands out blocks that work queued on
+        // the caller's stream may still be using): the copies are ordered behind that stream, as stage() orders the
+        // pack behind it and compare() the comparison
+        int orc = order_after_source();
+        if (orc != PGSD_SUCCESS)
+            return orc;
         for (size_t i = 0; i < count; i++)
             if (dst[i] != nullptr && src[i].second > 0)
                 HIP_TRY(hipMemcpyAsync(dst[i], src[i].first, src[i].second, hipMemcpyDefault, m_pack_stream));
@@ -1084,6 +1130,14 @@ class DevicePipeline
             if (!m_staged.empty() || !m_direct.empty())
                 return PGSD_SUCCESS; // packed chunks still wait for their place in the file
             idle = m_outstanding == 0 && m_reads_outstanding == 0 && m_jobs.empty();
+            }
+            {
+            // ... and so may chunks that were READ: between pgsd_read_chunk_device(wait = false) and
+            // pgsd_device_wait_read their bytes sit in the staging (arena or pinned direct arena) until the unpack
+            // launch has taken them -- a direct read counts no outstanding piece
+            std::lock_guard<std::mutex> g(m_copy_mutex);
+            if (!m_unpack_pending.empty())
+                return PGSD_SUCCESS;
             }
         const size_t soft_cap = (size_t)6 << 30;
         if (!idle && used < soft_cap)
@@ -1718,3 +1772,14 @@ void device_pipeline_stats(DevicePipeline* p, pgsd_device_stats* out, int reset)
     }
 
     } // namespace pgsd_amd
+
+extern "C" int pgsd_device_release_parked(void)
+    try
+    {
+    return pgsd_amd::release_parked_sets();
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return 0;
+    }

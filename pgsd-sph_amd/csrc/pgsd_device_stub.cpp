@@ -34,3 +34,5 @@ extern "C" int pgsd_device_available(void) { return 0; }
 extern "C" int pgsd_comm_rccl_unique_id(void*) { return PGSD_ERROR_NO_DEVICE; }
 extern "C" int pgsd_comm_init_rccl(const void*, int, int, int) { return PGSD_ERROR_NO_DEVICE; }
 extern "C" int pgsd_comm_create_rccl(const void*, int, int, int, struct pgsd_comm*) { return PGSD_ERROR_NO_DEVICE; }
+extern "C" int pgsd_comm_rccl_available(int) { return PGSD_ERROR_NO_DEVICE; }
+extern "C" int pgsd_device_release_parked(void) { return 0; }

@@ -252,7 +252,11 @@ struct Impl
         {
         n_collectives++;
         const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t serial = last_error_serial();
         const int rc = comm.allgather(comm.ctx, send, recv, bytes);
+        if (rc != 0) // what the back end said (a rank that is gone, ranks out of step, an exchange that timed out) is kept
+            set_last_error(last_error_serial() != serial ? std::string("communicator allgather failed: ") + last_error()
+                                                         : std::string("communicator allgather failed"));
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         exch_count++;
         exch_us_sum += us;
@@ -272,10 +276,7 @@ struct Impl
             return PGSD_SUCCESS;
             }
         if (gather(&v, out.data(), sizeof(uint64_t)) != 0)
-            {
-            set_last_error("communicator allgather failed");
             return PGSD_ERROR_COMM;
-            }
         return PGSD_SUCCESS;
         }
     };
@@ -315,10 +316,7 @@ static int agree_status(Impl* s, int local_rc)
     int32_t mine[2] = {local_rc, local_rc ? errno : 0};
     std::vector<int32_t> all((size_t)s->P * 2);
     if (s->gather(mine, all.data(), sizeof(mine)) != 0)
-        {
-        set_last_error("communicator allgather failed");
         return PGSD_ERROR_COMM;
-        }
     for (int r = 0; r < s->P; r++)
         if (all[(size_t)r * 2] != 0)
             {
@@ -852,7 +850,12 @@ static int flush_for_lookup(Impl* s)
     {
     if (s->flags == PGSD_OPEN_READONLY)
         return PGSD_SUCCESS;
-    if (metadata_pending(s))
+    // pgsd_set_local_reads covers the lookup that precedes the read: a frame that wrote buffered small
+    // chunks only -- everything else elided -- leaves metadata pending behind pgsd_end_frame (pgsd.c:1941-1950), and
+    // a rank that then looks one of frame 0's chunks up ALONE (it is the only one that compares that array) must not
+    // start the collective flush.  It sees what the last flush committed; chunks of frames still pending are
+    // not found until then.  (One rank: the flush is nobody else's business and runs as ever.)
+    if (metadata_pending(s) && (!s->local_reads || s->P == 1))
         return do_flush(s);
     return drain_own_copies(s);
     }
@@ -973,10 +976,7 @@ static int exchange_counts(Impl* s, uint64_t mine, int local_rc, std::vector<uin
     uint64_t send[2] = {mine, (uint64_t)(uint32_t)local_rc | ((uint64_t)(uint32_t)(local_rc ? errno : 0) << 32)};
     std::vector<uint64_t> recv((size_t)s->P * 2);
     if (s->gather(send, recv.data(), sizeof(send)) != 0)
-        {
-        set_last_error("communicator allgather failed");
         return PGSD_ERROR_COMM;
-        }
     int rc = PGSD_SUCCESS;
     for (int r = 0; r < s->P; r++)
         {
@@ -1193,8 +1193,6 @@ static int resolve_queue(Impl* s)
         recv.assign((size_t)FRAME_WORDS * (size_t)s->P, 0);
         TraceRange tr("pgsd:frame_exchange chunks=%llu ranks=%llu", k, (unsigned long long)s->P);
         bool comm_ok = s->gather(send.data(), recv.data(), FRAME_WORDS * sizeof(uint64_t)) == 0;
-        if (!comm_ok)
-            set_last_error("communicator allgather failed");
         for (int r = 0; r < s->P && comm_ok; r++)
             if (recv[(size_t)r * FRAME_WORDS + 1] != k)
                 {
@@ -1215,8 +1213,6 @@ static int resolve_queue(Impl* s)
             for (size_t i = base; i < k && i < base + FRAME_WORDS; i++)
                 send[i - base] = word_of(i);
             comm_ok = s->gather(send.data(), recv.data(), FRAME_WORDS * sizeof(uint64_t)) == 0;
-            if (!comm_ok)
-                set_last_error("communicator allgather failed");
             for (int r = 0; r < s->P && comm_ok; r++)
                 for (size_t i = base; i < k && i < base + FRAME_WORDS; i++)
                     words[(size_t)r * k + i] = recv[(size_t)r * FRAME_WORDS + (i - base)];
@@ -1465,10 +1461,7 @@ extern "C" int pgsd_handle_allgather(struct pgsd_handle* handle, const void* sen
         return PGSD_SUCCESS;
         }
     if (s->gather(send, recv, bytes) != 0)
-        {
-        set_last_error("communicator allgather failed");
         return PGSD_ERROR_COMM;
-        }
     return PGSD_SUCCESS;
     }
 catch (...)

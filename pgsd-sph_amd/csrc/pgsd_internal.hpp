@@ -16,6 +16,7 @@ namespace pgsd_amd
     {
 void set_last_error(const std::string& s);
 const char* last_error();
+uint64_t last_error_serial(); // grows with every set_last_error of this thread: "did the callee leave a message?"
 // Called from the catch-all of every C-ABI entry point (function-try-blocks): no C++ exception
 // crosses the boundary.  Maps the exception in flight to a pgsd_error and records its text.
 int abi_guard() noexcept;

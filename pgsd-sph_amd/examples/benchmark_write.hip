@@ -85,12 +85,23 @@ int main(int argc, char** argv)
     const char* comm_name = P > 1 ? "shm" : "self";
     if (argc > 5 && strcmp(argv[5], "rccl") == 0)
         {
-        // 128-byte id from rank 0 to everybody over the communicator of the launch, then switch
-        unsigned char id[128] = {0};
-        if (rank == 0)
-            CHECK(pgsd_comm_rccl_unique_id(id));
+        // 128-byte id from rank 0 to everybody over the communicator of the launch, then switch.  The same exchange
+        // carries every rank's "librccl loaded, device there" (byte 128): nobody enters ncclCommInitRank -- which
+        // waits for all ranks -- unless every rank can
+        unsigned char id[129] = {0};
+        int ready = pgsd_comm_rccl_available(rank % ndev);
+        if (ready == PGSD_SUCCESS && rank == 0)
+            ready = pgsd_comm_rccl_unique_id(id);
+        id[128] = ready == PGSD_SUCCESS;
         std::vector<unsigned char> all((size_t)P * sizeof(id));
         CHECK(pgsd_comm_allgather(id, all.data(), sizeof(id)));
+        for (int r = 0; r < P; r++)
+            if (!all[(size_t)r * sizeof(id) + 128])
+                {
+                fprintf(stderr, "rank %d: the RCCL back end is not available on rank %d%s%s\n", rank, r,
+                        r == rank ? ": " : "", r == rank ? pgsd_last_error_string() : "");
+                return 1;
+                }
         CHECK(pgsd_comm_init_rccl(all.data(), rank, P, rank % ndev));
         comm_name = "rccl";
         }

@@ -90,6 +90,16 @@ cdef _raise_on_error(int retval, extra, int err=0):
         raise RuntimeError("Unknown error: " + extra)
 
 
+def _device_index_of(field):
+    """GPU index of the array behind a field (a DeviceField made from a tensor keeps it alive; or a tensor), or None."""
+    keep = field.keepalive if isinstance(field, DeviceField) else field
+    for t in (keep if isinstance(keep, (list, tuple)) else [keep]):
+        index = getattr(getattr(t, 'device', None), 'index', None)
+        if index is not None:
+            return index
+    return None
+
+
 cdef class DeviceField:
     """Describe rows that live in GPU memory: ``chunk[i, c] = src[order[i]][col0 + c]``.
 
@@ -754,7 +764,8 @@ cdef class PGSDFile:
         finally:
             free(reqs)
         _raise_on_error(retval, self._name, err)
-        return (int(ticket), int(N), tuple(sizes))      # (ticket, rows, packed bytes of every chunk)
+        # (ticket, rows, packed bytes of every chunk, the GPU the sources -- and with them the staging -- live on)
+        return (int(ticket), int(N), tuple(sizes), _device_index_of(fields[0][1]))
 
     def write_staged(self, ticket, first, count, offset=None, rank=0):
         """Write chunks ``[first, first + count)`` of a :meth:`stage_chunks` ticket at this point of the frame
@@ -820,6 +831,13 @@ cdef class PGSDFile:
         pack (``pgsd_copy_staged_chunks``) -- references for :meth:`compare_staged` in later frames."""
         self._check_open()
         import torch
+        # The destinations come from torch's caching allocator: a recycled block may still be in use by work queued
+        # on torch's stream, so the copies (on the pack stream) are ordered behind that stream like every other
+        # device call that touches caller memory (ADVICE r3) -- and they live on the GPU the staging lives on, which
+        # need not be torch's current device.
+        if not self._explicit_stream:
+            self._sync_source_stream()
+        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else torch.cuda.current_device()
         cdef Py_ssize_t n = len(sizes), i
         if n == 0:
             return []
@@ -840,7 +858,7 @@ cdef class PGSDFile:
                 if sizes[i] is None:
                     out.append(None)
                     continue
-                t = torch.empty(int(sizes[i]), dtype=torch.uint8, device='cuda')
+                t = torch.empty(int(sizes[i]), dtype=torch.uint8, device=torch.device('cuda', device))
                 out.append(t)
                 p = t.data_ptr()
                 ptrs[i] = <void*>p

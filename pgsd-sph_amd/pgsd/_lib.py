@@ -170,6 +170,8 @@ _sig("pgsd_comm_init_shm", c_i32, c_cp, c_i32, c_i32)
 _sig("pgsd_comm_init_from_env", c_i32)
 _sig("pgsd_comm_rccl_unique_id", c_i32, c_vp)
 _sig("pgsd_comm_init_rccl", c_i32, c_vp, c_i32, c_i32, c_i32)
+_sig("pgsd_comm_rccl_available", c_i32, c_i32)
+_sig("pgsd_device_release_parked", c_i32)
 _sig("pgsd_comm_finalize", c_i32)
 _sig("pgsd_comm_rank", c_i32)
 _sig("pgsd_comm_size", c_i32)

@@ -62,15 +62,24 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
         if device is None:
             device = torch.cuda.current_device()
         where = "cuda:%d" % device if backend == "nccl" else "cpu"    # where the group's own collectives run
+        # First what every rank can know by itself: librccl loads, the device is there, rank 0 has an id.  The ranks
+        # agree on that BEFORE anyone enters ncclCommInitRank, which waits for all of them.
+        ready = lib.pgsd_comm_rccl_available(int(device))
+        err = _lib.last_error() if ready != 0 else ""
         uid = torch.zeros(128, dtype=torch.uint8, device=where)
-        if rank == 0:
+        if rank == 0 and ready == 0:
             buf = (ctypes.c_uint8 * 128)()
-            if lib.pgsd_comm_rccl_unique_id(buf) == 0:
+            ready = lib.pgsd_comm_rccl_unique_id(buf)
+            if ready == 0:
                 uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+            else:
+                err = _lib.last_error()
+        ok = torch.tensor([1 if ready == 0 else 0], dtype=torch.int32, device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise RuntimeError("the RCCL back end is not available on at least one rank: " + (err or "(another rank)"))
         dist.broadcast(uid, src=0, group=group)
         host = bytes(uid.cpu().tolist())
-        if not any(host):  # rank 0 could not produce an id: all ranks leave together
-            raise RuntimeError("pgsd_comm_rccl_unique_id failed on rank 0: " + _lib.last_error())
         rc = lib.pgsd_comm_init_rccl(host, rank, size, int(device))
         err = _lib.last_error() if rc != 0 else ""
         if rc == 0:

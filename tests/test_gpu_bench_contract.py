@@ -29,6 +29,7 @@ def test_bench_line_has_the_contracts_fields():
     assert d["dtype"] == "f32" and d["data"] == "synthetic"
     assert isinstance(d["value"], float) and d["value"] > 0 and d["ms_per_step"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["target_dir"] == "/dev/shm" and d["config"]["target_fstype"] == "tmpfs"
     assert d["comm_backend"] == "self" and d["collectives_per_frame"] == 0.0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -101,3 +102,16 @@ def test_declared_partition_run_costs_no_collective_per_frame():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert d["n_gpus"] == 2 and d["collectives_per_frame"] == 0.0 and "declared" in d["placement"]
     assert d["exchange_us"]["per_rank_count"] == 0 and d["value"] > 0
+
+
+def test_a_target_without_room_stops_the_run_instead_of_moving_it():
+    """when --dir lacks room rank 0 used to move the run to /tmp or the working directory
+    silently, so a 1 -> 8 curve could mix file systems.  Now the run stops with the figures unless --dir-fallback is
+    given (and names directory and file system type in the line either way)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "400000", "--warmup", "1",
+            "--particles", "10000000", "--traffic", "off", "--no-cpu-baseline"]        # 112 TB of frames
+    p = subprocess.run(base, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "has not that much room" in p.stderr and "--dir-fallback" in p.stderr and "nor /tmp" not in p.stderr
+    p = subprocess.run(base + ["--dir-fallback"], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "nor /tmp" in p.stderr

@@ -31,6 +31,7 @@ def run_worker(kind, P, path, what):
         product.build()
         assert os.path.exists(FAKE)
         env["PGSD_RCCL_LIBRARY"] = FAKE
+        env["PGSD_FAKE_RCCL_SYNC"] = "1"          # ranks as threads of one process: see fake_rccl.cpp
     p = subprocess.run([sys.executable, WORKER, kind, str(P), path, what], env=env, capture_output=True, text=True,
                        timeout=400)
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-3000:])
@@ -92,6 +93,7 @@ def test_eight_ranks_at_ten_million_particles_each_match_the_oracle(what, kind):
         product.build()
         assert os.path.exists(FAKE)
         env["PGSD_RCCL_LIBRARY"] = FAKE
+        env["PGSD_FAKE_RCCL_SYNC"] = "1"          # ranks as threads of one process: see fake_rccl.cpp
     p = subprocess.run([sys.executable, FULL, kind, str(P), str(n), what, d], env=env, capture_output=True, text=True,
                        timeout=600)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")]

@@ -79,6 +79,23 @@ def _worker(rank, world, port, path, counts, mode):
                 fr.particles.typeid = S.gen_data(3, seed, row0, n, 1)[:, 0] % 3 + 1
             t.append(fr)
         t.close()
+    elif mode == "hoomd_lone_compare":
+        # frame 1 writes nothing but the buffered step chunk (every array elided), so pgsd_end_frame does
+        # not flush and metadata stays pending; in frame 2 rank 0 ALONE compares an array it has not compared before
+        # (velocity: None on the other ranks) -- the lookup and read of frame 0's rows must stay local
+        t = hoomd.open(path, 'w')
+        pos = S.gen_data(9, 300, row0, n, 3)
+        vel = S.gen_data(9, 301, row0, n, 3)
+        for frame in range(4):
+            fr = hoomd.Frame()
+            fr.configuration.step = frame
+            fr.particles.N = n
+            fr.part_dist = np.array(counts)
+            fr.particles.position = pos
+            if frame == 0 or (frame >= 2 and rank == 0):
+                fr.particles.velocity = vel
+            t.append(fr)
+        t.close()
     else:
         t = hoomd.open(path, 'w')
         for frame in range(2):
@@ -224,3 +241,29 @@ def test_hoomd_append_rank_with_default_valued_fields(counts, tmp_path):
             tid = S.gen_data(3, seed, 0, Ng, 1)[:, 0] % 3 + 1
             tid[:n0] = 0
             np.testing.assert_array_equal(s.particles.typeid, tid)
+
+
+@pytest.mark.parametrize("counts", [[6, 3], [4, 2, 5]])
+def test_hoomd_append_one_rank_alone_compares_an_array_while_metadata_is_pending(counts, tmp_path):
+    """`_read_frame0_rows` is a local read, but the lookup in front of it ran the collective
+    flush whenever metadata was pending -- which is what a frame with every array elided leaves behind.  Rank 0 alone
+    compares its velocities in frames 2 and 3: the run must finish (it hung on RCCL / MPI, PGSD_ERROR_COMM on shm and
+    gloo) and the file hold frame 0's arrays once."""
+    P = len(counts)
+    mine = str(tmp_path / "traj.gsd")
+    tmp_mp.spawn(_worker, args=(P, free_port(), mine, counts, "hoomd_lone_compare"), nprocs=P, join=True)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgsd-sph_amd"))
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    Ng = sum(counts)
+    with hoomd.open(mine, 'r') as t:
+        assert len(t) == 4
+        for frame in range(4):
+            s = t[frame]
+            assert s.particles.N == Ng and s.configuration.step == frame
+            np.testing.assert_array_equal(s.particles.position, S.gen_data(9, 300, 0, Ng, 3))
+            np.testing.assert_array_equal(s.particles.velocity, S.gen_data(9, 301, 0, Ng, 3))
+    f = fl.open(mine, 'r')
+    for frame in (1, 2, 3):                     # everything but the step was elided
+        assert not f.chunk_exists(frame, 'particles/position') and not f.chunk_exists(frame, 'particles/velocity')
+    f.close()
