@@ -1,6 +1,6 @@
 /* scenario_driver.c -- replay a chunk-write scenario through the pgsd C ABI.
  *
- * Test infrastructure.  ONE source, THREE builds:
+ * Test infrastructure.  ONE source, FOUR builds:
  *
  *   -DPGSD_DRIVER_REF   links the reference's own pgsd.c (compiled in place from
  *                       /root/reference by oracle/Makefile, output in oracle/_ref/)
@@ -13,6 +13,16 @@
  *   -DPGSD_DRIVER_MPI   links libpgsd_amd.so AND MPI: the product under the reference's own
  *                       launcher (mpiexec), its collectives forwarded to MPI_Allgather through
  *                       the communicator vtable.
+ *
+ *   -DPGSD_DRIVER_DEVICE (a fourth build of the PRODUCT, needs the HIP runtime): as the default build, plus the
+ *                       script command `device <0|1|2>` -- from then on the rows of every chunk write are uploaded
+ *                       to HBM (1: as a dense N x M array; 2: inside wider rows, x/y/z of a Scalar4 and the like, so
+ *                       that the strided pack kernels run) and written through pgsd_write_chunk_device, the device
+ *                       twin of pgsd_write_chunk with the same arguments: every reference-written golden is then
+ *                       reproduced FROM HBM (tests/test_gpu_golden_device.py).
+ *   PGSD_DRIVER_THREADS=P (environment, default and device builds): the P ranks are P THREADS of this process, each
+ *                       with a communicator of its own (pgsd_comm_create_shm + pgsd_create_and_open_on) -- the GPU
+ *                       boxes admit six processes on the card, the goldens go up to eight ranks.
  *
  * All builds make exactly the same pgsd_* calls (the drop-in boundary of
  * /root/reference/pgsd/pgsd/pgsd.h:362-735), so `cmp` of the two output files is the
@@ -52,6 +62,8 @@
  *                                   ignored by the reference build.
  *                                   `dump` then performs the pending exchange first, so that the trace
  *                                   shows the same file_size the unbatched run shows)
+ *   device <0|1|2>                 (PGSD_DRIVER_DEVICE build only, see above; refused by the other product builds,
+ *                                   ignored by the reference build)
  *   end_frame | flush | close | dump
  *   maxbuf <bytes> | idxbuf <entries>
  *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
@@ -72,6 +84,12 @@
 
 #if defined(PGSD_DRIVER_REF) || defined(PGSD_DRIVER_MPI)
 #include <mpi.h>
+#else
+#include <pthread.h>
+#endif
+
+#ifdef PGSD_DRIVER_DEVICE
+#include <hip/hip_runtime_api.h>
 #endif
 
 #ifdef PGSD_DRIVER_MPI
@@ -89,7 +107,12 @@ static int mpi_barrier_cb(void* ctx)
     }
 #endif
 
-static int g_rank = 0, g_size = 1;
+/* per rank: a rank is a process -- or, with PGSD_DRIVER_THREADS, a thread */
+static __thread int g_rank = 0, g_size = 1;
+#if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
+static __thread struct pgsd_comm g_comm; /* thread ranks: this rank's own communicator */
+static __thread int g_own_comm = 0;
+#endif
 
 static uint64_t mix64(uint64_t seed, uint64_t gid, uint32_t c, uint32_t M)
     {
@@ -168,7 +191,8 @@ static void dist_counts(const char* dist, uint64_t* counts)
         char tmp[512];
         strncpy(tmp, dist + 5, sizeof(tmp) - 1);
         tmp[sizeof(tmp) - 1] = 0;
-        for (char* tok = strtok(tmp, ","); tok && nv < 64; tok = strtok(NULL, ","))
+        char* save = NULL; /* (strtok_r: the ranks may be threads) */
+        for (char* tok = strtok_r(tmp, ",", &save); tok && nv < 64; tok = strtok_r(NULL, ",", &save))
             vals[nv++] = strtoull(tok, NULL, 10);
         for (int r = 0; r < g_size; r++)
             counts[r] = vals[r % nv];
@@ -185,7 +209,16 @@ static void all_ranks_meet(void)
 #if defined(PGSD_DRIVER_REF) || defined(PGSD_DRIVER_MPI)
     MPI_Barrier(MPI_COMM_WORLD);
 #else
-    pgsd_comm_barrier();
+    if (g_own_comm)
+        {
+        char one = 0, all[1024];
+        if (g_comm.barrier)
+            g_comm.barrier(g_comm.ctx);
+        else
+            g_comm.allgather(g_comm.ctx, &one, all, 1);
+        }
+    else
+        pgsd_comm_barrier();
 #endif
     }
 
@@ -241,14 +274,17 @@ static enum pgsd_open_flag parse_flag(const char* s)
 
 /* rows of chunk writes that must outlive the call (batch 2: pgsd_set_deferred_rows): freed at the next
    end_frame / flush / close / dump, all of which resolve the queue */
-static int g_trusted = 0; /* batch 3 */
-static void* g_kept[65536];
-static int g_nkept = 0;
-static int g_defer = 0;
+static __thread int g_trusted = 0; /* batch 3 */
+static __thread void** g_kept = NULL;
+static __thread int g_nkept = 0;
+static __thread int g_defer = 0;
+#define KEPT_MAX 65536
 
 static void release_rows(void* data)
     {
-    if (g_defer && g_nkept < (int)(sizeof(g_kept) / sizeof(g_kept[0])))
+    if (g_defer && !g_kept)
+        g_kept = (void**)malloc(KEPT_MAX * sizeof(void*));
+    if (g_defer && g_nkept < KEPT_MAX)
         g_kept[g_nkept++] = data;
     else
         free(data);
@@ -260,6 +296,108 @@ static void free_kept_rows(void)
         free(g_kept[i]);
     g_nkept = 0;
     }
+
+/* ---- device rows (PGSD_DRIVER_DEVICE): what a chunk write passes instead of host rows ---- */
+#ifdef PGSD_DRIVER_DEVICE
+static __thread int g_device = 0; /* `device` command: 0 host rows, 1 dense device rows, 2 device rows inside wider rows */
+static __thread void** g_dev_kept = NULL; /* device arrays a queued or asynchronous chunk may still read: freed with the frame */
+static __thread int g_ndev_kept = 0;
+
+static void free_device_rows(void)
+    {
+    for (int i = 0; i < g_ndev_kept; i++)
+        (void)hipFree(g_dev_kept[i]); /* waits for the kernels that read it */
+    g_ndev_kept = 0;
+    }
+
+/* rows[N][M] of `sz`-byte elements -> device memory; mode 2: row i sits at elements [i * stride + col0, + M) of a
+   wider array whose other columns hold a pattern the chunk must not pick up */
+static int upload_rows(const void* rows, uint64_t N, uint32_t M, size_t sz, int type, struct pgsd_field_desc* d)
+    {
+    memset(d, 0, sizeof(*d));
+    d->src_type = (uint32_t)type;
+    d->src_stride = M;
+    if (N == 0 || M == 0 || !rows)
+        return 0;
+    uint32_t stride = M, col0 = 0;
+    if (g_device == 2)
+        {
+        stride = M == 3 ? 4 : M + 2; /* xyz of a Scalar4; otherwise one foreign column on either side */
+        col0 = M == 3 ? 0 : 1;
+        }
+    const size_t bytes = (size_t)N * stride * sz;
+    char* host = (char*)rows;
+    if (stride != M)
+        {
+        host = (char*)malloc(bytes);
+        memset(host, 0xA5, bytes);
+        for (uint64_t i = 0; i < N; i++)
+            memcpy(host + (i * stride + col0) * sz, (const char*)rows + i * M * sz, (size_t)M * sz);
+        }
+    void* dev = NULL;
+    int bad = hipMalloc(&dev, bytes) != hipSuccess || hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess;
+    if (host != rows)
+        free(host);
+    if (bad)
+        {
+        fprintf(stderr, "rank %d: cannot upload %zu bytes to the device\n", g_rank, bytes);
+        exit(4);
+        }
+    if (!g_dev_kept)
+        g_dev_kept = (void**)malloc(KEPT_MAX * sizeof(void*));
+    if (g_ndev_kept >= KEPT_MAX)
+        exit(4);
+    g_dev_kept[g_ndev_kept++] = dev;
+    d->src = dev;
+    d->src_stride = stride;
+    d->src_col0 = col0;
+    return 0;
+    }
+#endif
+
+/* THE chunk write of every chunk command: pgsd_write_chunk (pgsd.h:551-564) -- or its device twin with the same
+   arguments and the rows in HBM */
+static int write_rows(struct pgsd_handle* h, const char* name, int type, uint64_t N, uint32_t M, uint64_t Ng, uint32_t Mg,
+                      uint64_t off, uint64_t gs, int all, const void* data, size_t sz)
+    {
+#ifdef PGSD_DRIVER_DEVICE
+    if (g_device)
+        {
+        struct pgsd_field_desc d;
+        upload_rows(data, N, M, sz, type, &d);
+        return pgsd_write_chunk_device(h, name, (enum pgsd_type)type, N, M, Ng, Mg, off, gs, all != 0, 0, &d);
+        }
+#endif
+    (void)sz;
+    return pgsd_write_chunk(h, name, (enum pgsd_type)type, N, M, Ng, Mg, off, gs, all != 0, 0, data);
+    }
+
+static int run_script(const char* script, const char* path);
+
+#if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
+struct thread_rank
+    {
+    int rank, size, rc;
+    const char *shm, *script, *path;
+    };
+
+static void* thread_rank_main(void* p)
+    {
+    struct thread_rank* t = (struct thread_rank*)p;
+    g_rank = t->rank;
+    g_size = t->size;
+    if (pgsd_comm_create_shm(t->shm, t->rank, t->size, &g_comm) != PGSD_SUCCESS)
+        {
+        fprintf(stderr, "rank %d: pgsd_comm_create_shm failed: %s\n", t->rank, pgsd_last_error_string());
+        t->rc = 3;
+        return NULL;
+        }
+    g_own_comm = 1;
+    t->rc = run_script(t->script, t->path);
+    pgsd_comm_release(&g_comm);
+    return NULL;
+    }
+#endif
 
 int main(int argc, char** argv)
     {
@@ -287,6 +425,30 @@ int main(int argc, char** argv)
         return 3;
     }
 #else
+    const char* nthreads = getenv("PGSD_DRIVER_THREADS");
+    if (nthreads && atoi(nthreads) > 1)
+        {
+        /* the ranks are threads: one communicator, one handle and (device build) one pipeline each */
+        const int P = atoi(nthreads);
+        const char* shm = getenv("PGSD_SHM_NAME");
+        struct thread_rank* t = (struct thread_rank*)calloc((size_t)P, sizeof(*t));
+        pthread_t* th = (pthread_t*)calloc((size_t)P, sizeof(*th));
+        if (!shm || !t || !th)
+            return 3;
+        for (int r = 0; r < P; r++)
+            {
+            t[r].rank = r, t[r].size = P, t[r].shm = shm, t[r].script = argv[1], t[r].path = argv[2];
+            pthread_create(&th[r], NULL, thread_rank_main, &t[r]);
+            }
+        int worst = 0;
+        for (int r = 0; r < P; r++)
+            {
+            pthread_join(th[r], NULL);
+            if (t[r].rc > worst)
+                worst = t[r].rc;
+            }
+        return worst;
+        }
     if (pgsd_comm_init_from_env() != PGSD_SUCCESS)
         {
         fprintf(stderr, "pgsd_comm_init_from_env failed\n");
@@ -295,14 +457,26 @@ int main(int argc, char** argv)
     g_rank = pgsd_comm_rank();
     g_size = pgsd_comm_size();
 #endif
+    int rc_script = run_script(argv[1], argv[2]);
+#ifdef PGSD_DRIVER_REF
+    MPI_Finalize();
+#elif defined(PGSD_DRIVER_MPI)
+    pgsd_comm_finalize();
+    MPI_Finalize();
+#else
+    pgsd_comm_finalize();
+#endif
+    return rc_script;
+    }
 
-    FILE* f = fopen(argv[1], "r");
+static int run_script(const char* script, const char* path)
+    {
+    FILE* f = fopen(script, "r");
     if (!f)
         {
-        perror(argv[1]);
+        perror(script);
         return 2;
         }
-    const char* path = argv[2];
 
     struct pgsd_handle handle;
     uint64_t seed = 1;
@@ -317,7 +491,8 @@ int main(int argc, char** argv)
             *hash = 0;
         char* tok[16];
         int nt = 0;
-        for (char* t = strtok(line, " \t\r\n"); t && nt < 16; t = strtok(NULL, " \t\r\n"))
+        char* save = NULL;
+        for (char* t = strtok_r(line, " \t\r\n", &save); t && nt < 16; t = strtok_r(NULL, " \t\r\n", &save))
             tok[nt++] = t;
         if (nt == 0)
             continue;
@@ -325,17 +500,29 @@ int main(int argc, char** argv)
         const char* cmd = tok[0];
         if (strcmp(cmd, "prefill") == 0 && nt == 2)
             {
-            if (prefill(argv[1], tok[1], path) != 0)
+            if (prefill(script, tok[1], path) != 0)
                 return 2;
             }
         else if (strcmp(cmd, "create") == 0 && nt == 7)
             {
+#if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
+            if (g_own_comm)
+                rc = pgsd_create_and_open_on(&g_comm, &handle, path, tok[1], tok[2],
+                                             pgsd_make_version((unsigned)atoi(tok[3]), (unsigned)atoi(tok[4])),
+                                             parse_flag(tok[5]), atoi(tok[6]));
+            else
+#endif
             rc = pgsd_create_and_open(&handle, path, tok[1], tok[2],
                                       pgsd_make_version((unsigned)atoi(tok[3]), (unsigned)atoi(tok[4])),
                                       parse_flag(tok[5]), atoi(tok[6]));
             }
         else if (strcmp(cmd, "open") == 0 && nt == 2)
             {
+#if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
+            if (g_own_comm)
+                rc = pgsd_open_on(&g_comm, &handle, path, parse_flag(tok[1]));
+            else
+#endif
             rc = pgsd_open(&handle, path, parse_flag(tok[1]));
             }
         else if (strcmp(cmd, "seed") == 0 && nt == 2)
@@ -370,22 +557,19 @@ int main(int argc, char** argv)
             if (g_trusted && all)
                 {
                 data = gen_data(type, seed, row0, N, M, sz);
-                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, PGSD_PARTITION_AUTO, M, 0, 0, true, 0,
-                                      data);
+                rc = write_rows(&handle, tok[1], type, N, M, PGSD_PARTITION_AUTO, M, 0, 0, 1, data, sz);
                 }
             else
 #endif
             if (all)
                 {
                 data = gen_data(type, seed, row0, N, M, sz);
-                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M,
-                                      Ng * M, true, 0, data);
+                rc = write_rows(&handle, tok[1], type, N, M, Ng, M, row0 * M, Ng * M, 1, data, sz);
                 }
             else
                 {
                 data = gen_data(type, seed, 0, N, M, sz);
-                rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, N, M, 0, N * M,
-                                      false, 0, data);
+                rc = write_rows(&handle, tok[1], type, N, M, N, M, 0, N * M, 0, data, sz);
                 }
             release_rows(data);
             }
@@ -410,8 +594,7 @@ int main(int argc, char** argv)
             if (g_trusted)
                 pgsd_set_partition(&handle, NULL, 0);
 #endif
-            rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, M, row0 * M, gs, all != 0, 0,
-                                  data);
+            rc = write_rows(&handle, tok[1], type, N, M, Ng, M, row0 * M, gs, all, data, sz);
             release_rows(data);
             }
         else if ((strcmp(cmd, "rawchunk") == 0 || strcmp(cmd, "samechunk") == 0) && nt == 10)
@@ -430,24 +613,32 @@ int main(int argc, char** argv)
             if (g_trusted)
                 pgsd_set_partition(&handle, NULL, 0);
 #endif
-            rc = pgsd_write_chunk(&handle, tok[1], (enum pgsd_type)type, N, M, Ng, Mg, off, gs,
-                                  all != 0, 0, data);
+            rc = write_rows(&handle, tok[1], type, N, M, Ng, Mg, off, gs, all, data, sz);
             release_rows(data);
             }
         else if (strcmp(cmd, "end_frame") == 0)
             {
             rc = pgsd_end_frame(&handle);
             free_kept_rows();
+#ifdef PGSD_DRIVER_DEVICE
+            free_device_rows();
+#endif
             }
         else if (strcmp(cmd, "flush") == 0)
             {
             rc = pgsd_flush(&handle);
             free_kept_rows();
+#ifdef PGSD_DRIVER_DEVICE
+            free_device_rows();
+#endif
             }
         else if (strcmp(cmd, "close") == 0)
             {
             rc = pgsd_close(&handle);
             free_kept_rows();
+#ifdef PGSD_DRIVER_DEVICE
+            free_device_rows();
+#endif
             }
         else if (strcmp(cmd, "maxbuf") == 0 && nt == 2)
             rc = pgsd_set_maximum_write_buffer_size(&handle, strtoull(tok[1], NULL, 10));
@@ -468,6 +659,20 @@ int main(int argc, char** argv)
                 }
             else
                 g_defer = 0;
+#endif
+            }
+        else if (strcmp(cmd, "device") == 0 && nt == 2)
+            {
+#ifdef PGSD_DRIVER_DEVICE
+            g_device = atoi(tok[1]);
+            if (g_device && hipSetDevice(0) != hipSuccess)
+                {
+                fprintf(stderr, "rank %d: no HIP device\n", g_rank);
+                return 4;
+                }
+#elif !defined(PGSD_DRIVER_REF)
+            fprintf(stderr, "line %d: `device` needs the PGSD_DRIVER_DEVICE build\n", lineno);
+            return 2;
 #endif
             }
         else if (strcmp(cmd, "localreads") == 0 && nt == 2)
@@ -568,13 +773,11 @@ int main(int argc, char** argv)
             }
         }
     fclose(f);
-#ifdef PGSD_DRIVER_REF
-    MPI_Finalize();
-#elif defined(PGSD_DRIVER_MPI)
-    pgsd_comm_finalize();
-    MPI_Finalize();
-#else
-    pgsd_comm_finalize();
+#ifdef PGSD_DRIVER_DEVICE
+    free_device_rows();
 #endif
+    free_kept_rows();
+    free(g_kept);
+    g_kept = NULL;
     return rc_all ? 1 : 0;
     }

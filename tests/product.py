@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pgsd-sph_amd", "csrc")
 LIB = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
 DRIVER = os.path.join(CSRC, "build", "scenario_driver")
+DEVICE_DRIVER = os.path.join(CSRC, "build", "scenario_driver_device")      # rows of every chunk write from HBM
 
 _built = False
 
@@ -34,16 +35,20 @@ def build():
     return LIB
 
 
-def run_driver(script, out_path, P, timeout=120, allow_fail=False):
-    """Replay a scenario through the product's C ABI with P processes (shm communicator).
+def run_driver(script, out_path, P, timeout=120, allow_fail=False, driver=None, threads=False):
+    """Replay a scenario through the product's C ABI with P processes (shm communicator) -- or, `threads`, with the P
+    ranks as P threads of ONE process, each with a communicator of its own (PGSD_DRIVER_THREADS).
 
     Returns rank 0's stdout lines."""
     build()
     name = "pgsdtest_%s" % uuid.uuid4().hex[:12]
     procs = []
-    for r in range(P):
+    if threads and P > 1:
+        env = dict(os.environ, PGSD_DRIVER_THREADS=str(P), PGSD_SHM_NAME=name)
+        procs.append(subprocess.Popen([driver or DRIVER, script, out_path], env=env, stdout=subprocess.PIPE))
+    for r in range(0 if procs else P):
         env = dict(os.environ, PGSD_RANK=str(r), PGSD_NRANKS=str(P), PGSD_SHM_NAME=name)
-        procs.append(subprocess.Popen([DRIVER, script, out_path], env=env,
+        procs.append(subprocess.Popen([driver or DRIVER, script, out_path], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out = None
     try:
@@ -92,6 +97,26 @@ def local_reads_script(path, out_path):
             lines.append(line)
             if tok and tok[0] in ("create", "open"):
                 lines.append("localreads 1\n")
+    with open(out_path, "w") as f:
+        f.writelines(lines)
+    return out_path
+
+
+def device_script(path, out_path, mode=1, batch=0):
+    """The same scenario with the rows of every chunk write in HBM (`device <mode>` behind create / open; the
+    scenario_driver_device build): 1 = dense device arrays, 2 = rows inside wider arrays.  `batch` as in
+    :func:`batched_script`."""
+    lines = []
+    with open(path) as f:
+        for line in f:
+            tok = line.split("#", 1)[0].split()
+            if tok and tok[0] == "prefill" and not os.path.isabs(tok[1]):   # looked up beside the ORIGINAL script
+                line = "prefill %s\n" % os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(path)), "..", "files", tok[1]))
+            lines.append(line)
+            if tok and tok[0] in ("create", "open"):
+                lines.append("device %d\n" % mode)
+                if batch and tok[0] == "create" or (tok[0] == "open" and tok[1] != "ro" and batch):
+                    lines.append("batch %d\n" % batch)
     with open(out_path, "w") as f:
         f.writelines(lines)
     return out_path

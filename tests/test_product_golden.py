@@ -94,3 +94,15 @@ def test_local_reads_on_one_rank_change_nothing(name, tmp_gsd, tmp_path):
         assert f.read() == g.read()
     strip = lambda ls: [re.sub(r"line=\d+ ", "", ln) for ln in ls if "cmd=localreads" not in ln]
     assert strip(log) == strip(S.read_log(golden[:-4] + ".log"))
+
+
+@pytest.mark.parametrize("name,P", [c for c in S.golden_cases() if c[1] >= 4])
+def test_ranks_as_threads_match_reference_file(name, P, tmp_gsd):
+    """The same replay with the P ranks as P THREADS of one driver process, each on a communicator and a handle of
+    its own (pgsd_comm_create_shm + pgsd_create_and_open_on / pgsd_open_on; PGSD_DRIVER_THREADS) -- how one process
+    drives several GPUs, and how the GPU tests put eight ranks on a box that admits six GPU processes."""
+    golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
+    log = product.run_driver(S.scenario_path(name), tmp_gsd, P, allow_fail=_fails_on_purpose(golden), threads=True)
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        assert f.read() == g.read()
+    assert log == S.read_log(golden[:-4] + ".log")
