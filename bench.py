@@ -241,6 +241,62 @@ def fstype_of(path):
         return None
 
 
+def overlap_slowdown(f, fields, np, torch, frames=4):
+    """How much slower does a kernel run while a snapshot drains?  A queue of identical HBM-bound launches (copy of a
+    512 MiB tensor: every CU busy, 1 GiB of traffic each) on a stream of its own is timed with HIP events ALONE and
+    WHILE `frames` frames are appended with asynchronous seals and drained (`frame_sync`): the pack kernels, the
+    device->host blit kernels and the pwrite()s run beside it.  tools/overlap_probe.py is the long form (also an
+    fp32 GEMM queue); profiles/r04_overlap_*.  The reference has no counterpart: its data is host resident."""
+    try:
+        src = torch.empty(1 << 27, dtype=torch.float32, device="cuda").normal_()
+        dst = torch.empty_like(src)
+        side = torch.cuda.Stream()
+
+        def drain():
+            t0 = time.perf_counter()
+            for i in range(frames):
+                f.write_chunk("configuration/step", np.array([2 * 10 ** 6 + i], dtype=np.uint64), write_all=False)
+                f.write_chunks(fields, offset="auto")
+                f.end_frame(wait=False)
+                f.wait_packed()
+            f.frame_sync()
+            return time.perf_counter() - t0
+
+        def queue(n):
+            with torch.cuda.stream(side):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    dst.copy_(src)
+                e1.record()
+            return e0, e1
+
+        t_drain = drain()
+        e0, e1 = queue(20)
+        side.synchronize()
+        per = e0.elapsed_time(e1) / 20.0
+        n = max(20, int(t_drain * 1e3 * 0.9 / per))          # a queue about as long as the drain
+        alone, under, cover = [], [], []
+        for _ in range(2):
+            e0, e1 = queue(n)
+            side.synchronize()
+            alone.append(e0.elapsed_time(e1) / n)
+        for _ in range(2):
+            e0, e1 = queue(n)
+            dt = drain()
+            side.synchronize()
+            ms = e0.elapsed_time(e1)
+            under.append(ms / n)
+            cover.append(min(1.0, dt * 1e3 / ms))
+        a, u = min(alone), min(under)
+        return {"slowdown_pct": round((u / a - 1.0) * 100.0, 2), "kernel": "copy of 512 MiB (1 GiB of HBM traffic per launch)",
+                "launches": n, "ms_per_launch_alone": round(a, 4), "ms_per_launch_under_drain": round(u, 4),
+                "frames_drained": frames, "drain_covers_fraction_of_queue": round(min(cover), 3)}
+    except Exception as e:  # a measurement aside: never fails the run
+        print("bench.py: overlap measurement failed (%s)" % e, file=sys.stderr)
+        return None
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched N-rank run: start N children of this script with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set (what torch.distributed.run would export), pass rank 0's stdout through and
@@ -526,7 +582,7 @@ def main():
 
     # What a simulation is blocked for per snapshot when it seals frames asynchronously: issue the
     # frame, wait for the pack kernels only (the arrays may then change), let copy + write run on.
-    stall_ms = None
+    stall_ms, overlap = None, None
     if world == 1 and not args.no_stall_test:
         stalls = []
         for i in range(3):
@@ -540,6 +596,9 @@ def main():
             stalls.append((time.perf_counter() - t1) * 1e3)
         f.frame_sync()
         stall_ms = round(min(stalls), 3)
+        # ... and what the draining snapshot costs the kernels that run meanwhile (the copies are shader blits,
+        # __amd_rocclr_copyBuffer: they share the CUs with the simulation)
+        overlap = overlap_slowdown(f, fields, np, torch)
     f.close()
 
     exch_mean = xstats["total_us"] / max(xstats["count"], 1)
@@ -633,6 +692,8 @@ def main():
                            "note": "n_gpus x the slowest rank's pack kernel rate: a sum of independent per-GPU rates "
                                    "(nothing shared is measured by it); `value` is the shared-file rate"},
         "snapshot_stall_ms": stall_ms,
+        "snapshot_overlap_slowdown_pct": overlap["slowdown_pct"] if overlap else None,
+        "snapshot_overlap": overlap,
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }

@@ -459,20 +459,27 @@ extern "C"
     /* Elision for arrays that live in HBM.  pgsd.hoomd does not write a per-particle array that equals frame 0's
        (reference: hoomd.py:654-694, a numpy comparison of host arrays).  For device arrays the test runs on the
        GPU, on staged chunks that have not been written yet:
-       pgsd_compare_staged_chunks compares the PACKED bytes of chunks [first, first + count) of a ticket with
+       pgsd_compare_staged_chunks compares the PACKED rows of chunks [first, first + count) of a ticket with
        ref[i] -- device memory holding the same rows of the other frame as the chunk stores them, N * M *
        sizeof(type) bytes (read with pgsd_read_chunk_device, or kept with pgsd_copy_staged_chunks) -- and sets
-       equal[i] = 1 when every byte matches, 0 when not or when ref[i] is NULL (a rank without rows: 1).  One
-       kernel launch behind the pack -- and behind whatever the caller's source stream
+       equal[i] = 1 when they are equal, 0 when not or when ref[i] is NULL (a rank without rows: 1).
+       ref_bytes (may be NULL): what ref[i] holds.  A reference SHORTER than the chunk REPEATS -- byte j of the chunk
+       is compared with byte j % ref_bytes[i] -- so a few thousand rows of a default value stand for any number of
+       rows (the "equals the default and frame 0 has no such chunk" half of hoomd.py:654-694); such a reference is
+       16-byte aligned and at least 4096 bytes, a multiple of 16 bytes and of whole rows.
+       Equality is numpy.array_equal's (hoomd.py:679-682): integer chunks by their bytes, float / double chunks by
+       VALUE -- a NaN equals nothing, itself included; +0.0 equals -0.0 -- so the decision is the one the reference's
+       host comparison takes for the same values.
+       One kernel launch behind the pack -- and behind whatever the caller's source stream
        (pgsd_device_set_source_stream) holds, like the pack itself: the references may have been written there a
        moment ago --, one stream wait; local, no collective: the caller agrees the outcome over the ranks like any
        other write / skip decision and then writes (pgsd_write_staged_chunks) or does not (unwritten chunks are
-       dropped by pgsd_end_frame).  Byte equality: NaNs with equal bits are equal, -0.0 and
-       0.0 are not -- eliding is always safe, a reader gets the same bits back from frame 0.
+       dropped by pgsd_end_frame).
        pgsd_copy_staged_chunks copies the packed bytes into caller-owned device memory dst[i] (NULL: skipped),
-       asynchronously behind the pack: complete after pgsd_device_wait_packed, a comparison or pgsd_end_frame. */
+       asynchronously behind the pack (and behind the caller's source stream: the destinations are the caller's):
+       complete after pgsd_device_wait_packed, a comparison or pgsd_end_frame. */
     int pgsd_compare_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
-                                   const void* const* ref, uint8_t* equal);
+                                   const void* const* ref, const uint64_t* ref_bytes, uint8_t* equal);
     int pgsd_copy_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
                                 void* const* dst);
 

@@ -5,9 +5,17 @@
 //                 a 0.3-1.6 GB snapshot copy cheap, and the simulation only has to wait for
 //                 the ~100 us pack, not for the file write)
 //   copy stream   waits for the pack event, then streams the staged bytes piece by piece
-//                 into a ring of pinned host slabs with hipMemcpyAsync (SDMA engine), so
-//                 the copy of piece k+1 overlaps the file write of piece k and the pack
-//                 of the next chunk
+//                 into a ring of pinned host slabs with hipMemcpyAsync, so the copy of piece
+//                 k+1 overlaps the file write of piece k and the pack of the next chunk.
+//                 On the MI355X boxes of this project the runtime executes these copies as
+//                 SHADER BLITS, not on an SDMA engine: they appear in the kernel trace as
+//                 __amd_rocclr_copyBuffer (240 dispatches of ~256 us for 12 frames of 10 M
+//                 particles, profiles/r03_kernel_stats_10M.csv) and share the CUs with whatever
+//                 the simulation runs.  They are PCIe-bound (50-55 GB/s) and need few CUs:
+//                 a queue of HBM-bound kernels runs 0.7 % slower while snapshots drain, an
+//                 fp32 GEMM queue 0.25 % (tools/overlap_probe.py, profiles/r04_overlap_probe.jsonl;
+//                 bench.py reports it as snapshot_overlap_slowdown_pct) -- which is why no SDMA
+//                 route was built
 //   writer pool   each piece is pwrite()n at the file offset the reference's
 //                 MPI_File_write_at would use (pgsd.c:2225-2229) as soon as its copy event
 //                 has fired; the slab then returns to the ring
@@ -17,7 +25,7 @@
 // Small frames take a shorter road (the "direct" path): when the chunks of one fused launch hold at most
 // PGSD_DIRECT_MAX_KIB (default 2048 KiB) the kernel packs them straight into a pinned, device-mapped host
 // arena -- the stores cross PCIe themselves -- and the bytes are pwrite()n by the thread that calls drain()
-// after ONE stream wait: no HBM staging, no SDMA copy, no dispatcher / writer hand-over.  For a snapshot of a
+// after ONE stream wait: no HBM staging, no device->host copy, no dispatcher / writer hand-over.  For a snapshot of a
 // few thousand particles those fixed costs were several times the frame itself (round 2: 176 us against 67 us
 // for the same frame from host arrays).  HIP events come from a pool instead of being created per launch.
 #include "pgsd_internal.hpp"
@@ -669,7 +677,7 @@ class DevicePipeline
 
     // Packed bytes of staged (not yet committed) chunks against reference bytes in device memory: one kernel behind
     // the pack on the pack stream, one stream wait, the answers in pinned words the kernel wrote across PCIe.
-    int compare(int ticket, size_t first, size_t count, const void* const* ref, uint8_t* equal)
+    int compare(int ticket, size_t first, size_t count, const void* const* ref, const uint64_t* ref_bytes, uint8_t* equal)
         {
         if (!m_ok)
             return PGSD_ERROR_NO_DEVICE;
@@ -690,7 +698,22 @@ class DevicePipeline
                 equal[i] = ref[i] != nullptr && bytes == 0 ? 1 : 0; // no rows here: nothing that could differ
                 if (ref[i] != nullptr && bytes > 0)
                     {
-                    jobs.push_back({c.job.dst, ref[i], bytes});
+                    CompareJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.a = c.job.dst;
+                    j.b = ref[i];
+                    j.bytes = bytes;
+                    j.mode = c.job.dst_type == PGSD_TYPE_FLOAT ? CMP_F32 : c.job.dst_type == PGSD_TYPE_DOUBLE ? CMP_F64 : CMP_BYTES;
+                    if (ref_bytes && ref_bytes[i] < bytes)
+                        {
+                        // a reference shorter than the chunk repeats: whole 16-byte vectors, whole elements, and long
+                        // enough for the kernel's one-step wrap (256 vectors)
+                        const uint64_t p = ref_bytes[i];
+                        if (p < 4096 || p % 16 != 0 || p % sizeof_type(c.job.dst_type) != 0 || ((uintptr_t)ref[i] & 15) != 0)
+                            return PGSD_ERROR_INVALID_ARGUMENT;
+                        j.period = p;
+                        }
+                    jobs.push_back(j);
                     who.push_back(i);
                     }
                 }
@@ -1696,9 +1719,9 @@ int device_pipeline_commit(DevicePipeline* p, int ticket, size_t index, long lon
     }
 
 int device_pipeline_compare(DevicePipeline* p, int ticket, size_t first, size_t count, const void* const* ref,
-                            uint8_t* equal, std::string* err)
+                            const uint64_t* ref_bytes, uint8_t* equal, std::string* err)
     {
-    int rc = p->compare(ticket, first, count, ref, equal);
+    int rc = p->compare(ticket, first, count, ref, ref_bytes, equal);
     if (rc != PGSD_SUCCESS && err)
         *err = p->error();
     return rc;

@@ -17,7 +17,7 @@ void device_pipeline_destroy(DevicePipeline*) { }
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, int*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_commit(DevicePipeline*, int, size_t, long long, void*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
-int device_pipeline_compare(DevicePipeline*, int, size_t, size_t, const void* const*, uint8_t*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
+int device_pipeline_compare(DevicePipeline*, int, size_t, size_t, const void* const*, const uint64_t*, uint8_t*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_copy_staged(DevicePipeline*, int, size_t, size_t, void* const*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 void device_pipeline_kick(DevicePipeline*) { }
 void device_pipeline_write_host(DevicePipeline*, const void*, size_t, long long) { }

@@ -2665,7 +2665,7 @@ static int staged_range(Impl* s, uint64_t ticket, uint32_t first, uint32_t count
     }
 
 extern "C" int pgsd_compare_staged_chunks(struct pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
-                                          const void* const* ref, uint8_t* equal)
+                                          const void* const* ref, const uint64_t* ref_bytes, uint8_t* equal)
     try
     {
     Impl* s = impl_of(handle);
@@ -2679,7 +2679,7 @@ extern "C" int pgsd_compare_staged_chunks(struct pgsd_handle* handle, uint64_t t
     if (e->local_rc != PGSD_SUCCESS || e->ticket < 0)
         return e->local_rc != PGSD_SUCCESS ? e->local_rc : PGSD_ERROR_DEVICE; // the staging failed: nothing to compare
     std::string err;
-    rc = device_pipeline_compare(s->dev, e->ticket, first, count, ref, equal, &err);
+    rc = device_pipeline_compare(s->dev, e->ticket, first, count, ref, ref_bytes, equal, &err);
     if (rc != PGSD_SUCCESS)
         {
         set_last_error(err);

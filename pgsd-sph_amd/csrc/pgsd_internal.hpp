@@ -112,10 +112,11 @@ int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, ui
 int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, int* ticket, std::string* err);
 int device_pipeline_commit(DevicePipeline*, int ticket, size_t index, long long file_offset, void* host_dst,
                            std::string* err);
-// staged, not yet committed chunks [first, first + count) of a ticket: packed bytes == ref[i] (device memory)?
+// staged, not yet committed chunks [first, first + count) of a ticket: packed rows == ref[i] (device memory; shorter
+// than the chunk: repeating)?
 // (one kernel + one stream wait) / copied into dst[i] (device memory, asynchronous on the pack stream)
 int device_pipeline_compare(DevicePipeline*, int ticket, size_t first, size_t count, const void* const* ref,
-                            uint8_t* equal, std::string* err);
+                            const uint64_t* ref_bytes, uint8_t* equal, std::string* err);
 int device_pipeline_copy_staged(DevicePipeline*, int ticket, size_t first, size_t count, void* const* dst,
                                 std::string* err);
 // asynchronous seal: chunks of the direct (small-frame) path are handed to the writer thread now

@@ -1130,16 +1130,113 @@ __global__ __launch_bounds__(256) void fill_cols_kernel(const FillArgs a)
         }
     }
 
-// ------------------------------------------------------------------ packed chunk == reference bytes ?
-// pgsd.hoomd elides a per-particle array that equals frame 0's (hoomd.py:654-694).  For arrays that live in HBM the
-// test runs here: the chunk is packed as usual, then its packed bytes are compared with the reference rows (also in
-// device memory) -- 16 bytes per lane and load, four loads of each side in flight, grid-stride.  Bandwidth-bound when the
-// arrays are equal (2 x chunk bytes read, nothing written).  Arrays that differ differ early, so a PROBE launch -- four
-// workgroups per job over its first 64 KiB -- runs first: the full launch's workgroups of a job the probe marked leave
-// at once (had they all found the difference themselves, thousands of waves would each have sent their mark across
-// PCIe: 237 us for two moving arrays of 10 M rows against 129 us for six equal ones).  A difference further in is still
-// found by the full launch; the first workgroup to see it marks the job and the others stop at their next stride.
-// The flag words are never cleared: a launch marks with its own generation number.
+// ------------------------------------------------------------------ packed chunk == reference rows ?
+// pgsd.hoomd elides a per-particle array that equals frame 0's, or the schema's default where frame 0 has no such chunk
+// (hoomd.py:654-694: numpy.array_equal / a broadcast comparison).  For arrays that live in HBM the test runs here: the
+// chunk is packed as usual, then its packed bytes are compared with the reference rows (also in device memory) -- 16
+// bytes per lane and load, four loads of each side in flight, grid-stride.  Bandwidth-bound when the arrays are equal
+// (2 x chunk bytes read -- 1 x against a short REPEATING reference, which stays in the L2 --, nothing written).
+// Equality is numpy's: integer chunks by their bytes, float chunks by VALUE -- a NaN differs from everything, itself
+// included, +0.0 equals -0.0 -- decided on the bit patterns (no floating-point instruction, so no denormal mode can
+// come into it).  Arrays that differ differ early, so a PROBE launch -- four workgroups per job over its first 64
+// KiB -- runs first: the full launch's workgroups of a job the probe marked leave at once (had they all found the
+// difference themselves, thousands of waves would each have sent their mark across PCIe: 237 us for two moving arrays
+// of 10 M rows against 129 us for six equal ones).  A difference further in is still found by the full launch; the
+// first workgroup to see it marks the job and the others stop at their next stride.  The flag words are never
+// cleared: a launch marks with its own generation number.
+template <int MODE> __device__ __forceinline__ uint32_t cmp_differ16(const u32x4 x, const u32x4 y)
+    {
+    if (MODE == CMP_BYTES)
+        return (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    if (MODE == CMP_F32)
+        {
+        // per word: differ = (bits differ and not both zeros of either sign) or the chunk's word is a NaN
+        // (a NaN in the reference alone differs in its bits anyway)
+        const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            {
+            const uint32_t mag = (a[k] | b[k]) & 0x7fffffffu;
+            acc |= ((a[k] ^ b[k]) != 0 && mag != 0) ? 1u : 0u;
+            acc |= ((a[k] & 0x7fffffffu) > 0x7f800000u) ? 1u : 0u;
+            }
+        return acc;
+        }
+    // CMP_F64: two doubles per vector, little endian (low word first)
+    uint32_t acc = 0;
+    const uint32_t al[2] = {x.x, x.z}, ah[2] = {x.y, x.w}, bl[2] = {y.x, y.z}, bh[2] = {y.y, y.w};
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        {
+        const uint32_t differ = (al[k] ^ bl[k]) | (ah[k] ^ bh[k]);
+        const uint32_t mag = ((ah[k] | bh[k]) & 0x7fffffffu) | al[k] | bl[k];
+        acc |= (differ != 0 && mag != 0) ? 1u : 0u;
+        const uint32_t am = ah[k] & 0x7fffffffu;
+        acc |= (am > 0x7ff00000u || (am == 0x7ff00000u && al[k] != 0)) ? 1u : 0u;
+        }
+    return acc;
+    }
+
+// one element of `es` bytes (1: a byte of an integer chunk) at byte offset `at`, assembled from bytes: the slow road of
+// unaligned pointers and of the last bytes
+__device__ __forceinline__ bool cmp_differ_element(const char* pa, const char* pb, uint64_t at, uint64_t at_b, uint32_t es,
+                                                   uint32_t mode)
+    {
+    uint64_t a = 0, b = 0;
+    for (uint32_t k = 0; k < es; k++)
+        {
+        a |= (uint64_t)(uint8_t)pa[at + k] << (8 * k);
+        b |= (uint64_t)(uint8_t)pb[at_b + k] << (8 * k);
+        }
+    if (mode == CMP_F32)
+        return ((a ^ b) != 0 && ((a | b) & 0x7fffffffull) != 0) || (a & 0x7fffffffull) > 0x7f800000ull;
+    if (mode == CMP_F64)
+        return ((a ^ b) != 0 && ((a | b) & 0x7fffffffffffffffull) != 0) || (a & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+    return a != b;
+    }
+
+template <int MODE, bool PERIODIC>
+__device__ __forceinline__ bool cmp_vector_loop(const u32x4* a, const u32x4* b, uint64_t n16, uint64_t period16, const uint32_t* df,
+                                                uint32_t gen)
+    {
+    const uint64_t per_block = 256 * 4;
+    for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n16; base += (uint64_t)gridDim.x * per_block)
+        {
+        if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
+            return false; // somebody else has the answer
+        // a repeating reference: ONE modulo per lane and stride, the three further vectors by a conditional step back
+        // (period16 >= 256 is checked by the host)
+        uint64_t bi = PERIODIC ? (base + threadIdx.x) % period16 : 0;
+        u32x4 x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            {
+            const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+            x[k] = (u32x4)(0u);
+            y[k] = (u32x4)(0u);
+            if (i < n16)
+                {
+                x[k] = __builtin_nontemporal_load(a + i);
+                y[k] = PERIODIC ? b[bi] : __builtin_nontemporal_load(b + i);
+                }
+            if (PERIODIC)
+                {
+                bi += 256;
+                if (bi >= period16)
+                    bi -= period16;
+                }
+            }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            acc |= cmp_differ16<MODE>(x[k], y[k]);
+        if (acc != 0)
+            return true;
+        }
+    return false;
+    }
+
 __global__ __launch_bounds__(256) void compare_bytes_kernel(const CompareArgs args)
     {
     CompareJob jb = args.j[blockIdx.y];
@@ -1157,39 +1254,22 @@ __global__ __launch_bounds__(256) void compare_bytes_kernel(const CompareArgs ar
         const u32x4* a = (const u32x4*)pa;
         const u32x4* b = (const u32x4*)pb;
         const uint64_t n16 = jb.bytes >> 4;
+        const uint64_t p16 = jb.period >> 4;
         done = n16 << 4;
-        const uint64_t per_block = 256 * 4;
-        for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n16; base += (uint64_t)gridDim.x * per_block)
-            {
-            if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == args.gen)
-                break;
-            u32x4 x[4], y[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                {
-                const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-                x[k] = (u32x4)(0u);
-                y[k] = (u32x4)(0u);
-                if (i < n16)
-                    {
-                    x[k] = __builtin_nontemporal_load(a + i);
-                    y[k] = __builtin_nontemporal_load(b + i);
-                    }
-                }
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                acc |= (x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w);
-            if (acc != 0)
-                {
-                diff = true;
-                break;
-                }
-            }
+        if (jb.period == 0)
+            diff = jb.mode == CMP_F32   ? cmp_vector_loop<CMP_F32, false>(a, b, n16, 0, df, args.gen)
+                   : jb.mode == CMP_F64 ? cmp_vector_loop<CMP_F64, false>(a, b, n16, 0, df, args.gen)
+                                        : cmp_vector_loop<CMP_BYTES, false>(a, b, n16, 0, df, args.gen);
+        else
+            diff = jb.mode == CMP_F32   ? cmp_vector_loop<CMP_F32, true>(a, b, n16, p16, df, args.gen)
+                   : jb.mode == CMP_F64 ? cmp_vector_loop<CMP_F64, true>(a, b, n16, p16, df, args.gen)
+                                        : cmp_vector_loop<CMP_BYTES, true>(a, b, n16, p16, df, args.gen);
         }
-    // what the vector loop left: the last bytes, or everything when a side is not 16-byte aligned
-    for (uint64_t i = done + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < jb.bytes && !diff; i += (uint64_t)gridDim.x * 256)
-        diff = pa[i] != pb[i];
+    // what the vector loop left: the last bytes, or everything when a side is not 16-byte aligned -- element by element
+    const uint32_t es = jb.mode == CMP_F32 ? 4u : jb.mode == CMP_F64 ? 8u : 1u;
+    for (uint64_t i = done + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * es; i + es <= jb.bytes && !diff;
+         i += (uint64_t)gridDim.x * 256 * es)
+        diff = cmp_differ_element(pa, pb, i, jb.period ? i % jb.period : i, es, jb.mode);
     const uint64_t who = __ballot(diff);
     if (who != 0 && (uint32_t)(__ffsll((unsigned long long)who) - 1) == (threadIdx.x & 63u))
         {

@@ -215,17 +215,29 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
 int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStream_t stream, std::string* err,
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
-// ---- byte comparison of packed chunks with reference bytes (pgsd_compare_staged_chunks)
+// ---- comparison of packed chunks with reference rows (pgsd_compare_staged_chunks)
 enum
     {
     CMP_MAX_JOBS = 64
     };
 
+enum
+    {
+    CMP_BYTES = 0, // integers: equal bytes
+    CMP_F32 = 1,   // float chunks are compared by VALUE, as numpy.array_equal compares them (hoomd.py:679-682):
+    CMP_F64 = 2    // a NaN equals nothing (itself included), +0.0 equals -0.0
+    };
+
 struct CompareJob
     {
-    const void* a;  // packed chunk (staging: HBM, or the pinned arena of the direct path)
-    const void* b;  // reference bytes in device memory
-    uint64_t bytes;
+    const void* a;   // packed chunk (staging: HBM, or the pinned arena of the direct path)
+    const void* b;   // reference in device memory
+    uint64_t bytes;  // of the chunk
+    uint64_t period; // 0: the reference holds `bytes` bytes; else it holds `period` bytes (a multiple of 16 and of the
+                     // element size) and REPEATS: byte j of the chunk is compared with byte j % period of the reference
+                     // (a few thousand rows of a default value stand for any number of rows)
+    uint32_t mode;   // CMP_*
+    uint32_t pad;
     };
 
 struct CompareArgs

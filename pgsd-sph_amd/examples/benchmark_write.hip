@@ -163,7 +163,7 @@ int main(int argc, char** argv)
                 CHECK(pgsd_copy_staged_chunks(&h, ticket, 0, 4, frame0_rows));
                 }
             else
-                CHECK(pgsd_compare_staged_chunks(&h, ticket, 0, 4, frame0_rows, same));
+                CHECK(pgsd_compare_staged_chunks(&h, ticket, 0, 4, frame0_rows, NULL, same));
             // a chunk is skipped only when EVERY rank found its rows unchanged
             std::vector<uint8_t> votes((size_t)P * 4);
             CHECK(pgsd_comm_allgather(same, votes.data(), 4));

@@ -782,10 +782,13 @@ cdef class PGSDFile:
         _raise_on_error(retval, self._name, err)
 
     def compare_staged(self, ticket, first, refs):
-        """Are the packed bytes of staged chunks ``first, first + 1, ...`` of a :meth:`stage_chunks` ticket equal to
+        """Do the packed rows of staged chunks ``first, first + 1, ...`` of a :meth:`stage_chunks` ticket equal
         ``refs[i]`` -- torch GPU tensors holding the same rows of another frame as the chunk stores them
-        (:meth:`read_chunk_device`, :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  One kernel behind the
-        pack, one stream wait (``pgsd_compare_staged_chunks``).  Byte equality.  Returns a list of bool."""
+        (:meth:`read_chunk_device`, :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  A reference SHORTER
+        than the chunk repeats (rows of a default value: at least 4096 bytes, a multiple of 16 bytes and of whole
+        rows).  One kernel behind the pack, one stream wait (``pgsd_compare_staged_chunks``).  Equality is
+        ``numpy.array_equal``'s: integer chunks by their bytes, float chunks by value (a NaN equals nothing, +0.0 equals
+        -0.0).  Returns a list of bool."""
         self._check_open()
         if not self._explicit_stream:
             self._sync_source_stream()      # the comparison is ordered behind this stream's writes to the references
@@ -795,11 +798,13 @@ cdef class PGSDFile:
         cdef uint64_t c_ticket = ticket[0], rows = ticket[1]
         cdef uint32_t c_first = first, c_count = n
         cdef const void** ptrs = <const void**>calloc(n, sizeof(void*))
+        cdef uint64_t* sizes = <uint64_t*>calloc(n, sizeof(uint64_t))
         cdef uint8_t* eq = <uint8_t*>calloc(n, 1)
         cdef uintptr_t p
         cdef int retval, err
-        if ptrs == NULL or eq == NULL:
+        if ptrs == NULL or eq == NULL or sizes == NULL:
             free(ptrs)
+            free(sizes)
             free(eq)
             raise MemoryError()
         try:
@@ -809,20 +814,25 @@ cdef class PGSDFile:
                     continue
                 if not _is_device_tensor(r) or not r.is_contiguous():
                     raise ValueError("a reference must be a contiguous torch GPU tensor (or None)")
-                if first + i >= len(ticket[2]) or r.numel() * r.element_size() != ticket[2][first + i]:
+                if first + i >= len(ticket[2]):
+                    raise ValueError("the ticket has no chunk %d" % (first + i))
+                have = r.numel() * r.element_size()
+                if have > ticket[2][first + i]:
                     # the kernel reads as many bytes of the reference as the packed chunk has: never fewer at hand
-                    raise ValueError("reference %d must hold the %d bytes of the packed chunk"
-                                     % (i, ticket[2][first + i] if first + i < len(ticket[2]) else -1))
+                    # (a shorter one repeats; the library checks its shape)
+                    raise ValueError("reference %d holds more than the %d bytes of the packed chunk" % (i, ticket[2][first + i]))
+                sizes[i] = have
                 p = r.data_ptr()
                 # an empty tensor has no address: any non-null one says "there is a reference" (no byte is read)
                 ptrs[i] = <const void*>p if p != 0 else <const void*>ptrs
             with nogil:
-                retval = C.pgsd_compare_staged_chunks(&self._handle, c_ticket, c_first, c_count, ptrs, eq)
+                retval = C.pgsd_compare_staged_chunks(&self._handle, c_ticket, c_first, c_count, ptrs, sizes, eq)
                 err = errno
             _raise_on_error(retval, self._name, err)
             return [bool(eq[i]) for i in range(n)]
         finally:
             free(ptrs)
+            free(sizes)
             free(eq)
 
     def copy_staged(self, ticket, first, sizes):

@@ -189,7 +189,8 @@ _sig("pgsd_write_chunk_device", c_i32, HP, c_cp, c_i32, c_u64, c_u32, c_u64, c_u
 _sig("pgsd_write_chunks_device", c_i32, HP, c_u32, ctypes.POINTER(ChunkReq), c_u64, c_u64, c_u64)
 _sig("pgsd_stage_chunks_device", c_i32, HP, c_u32, ctypes.POINTER(ChunkReq), c_u64, ctypes.POINTER(c_u64))
 _sig("pgsd_write_staged_chunks", c_i32, HP, c_u64, c_u32, c_u32, c_u64, c_u64)
-_sig("pgsd_compare_staged_chunks", c_i32, HP, c_u64, c_u32, c_u32, ctypes.POINTER(c_vp), ctypes.POINTER(c_u8))
+_sig("pgsd_compare_staged_chunks", c_i32, HP, c_u64, c_u32, c_u32, ctypes.POINTER(c_vp), ctypes.POINTER(c_u64),
+     ctypes.POINTER(c_u8))
 _sig("pgsd_copy_staged_chunks", c_i32, HP, c_u64, c_u32, c_u32, ctypes.POINTER(c_vp))
 _sig("pgsd_device_wait_packed", c_i32, HP)
 _sig("pgsd_device_set_source_stream", c_i32, HP, c_vp)

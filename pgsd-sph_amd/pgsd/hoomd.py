@@ -17,6 +17,7 @@ from one allgather over the installed communicator (RCCL over xGMI on GPU ranks)
 from collections import OrderedDict
 import json
 import logging
+import hashlib
 import warnings
 
 import numpy
@@ -351,6 +352,36 @@ def _encode_strings(strings):
     return b.view(dtype=numpy.int8).reshape(len(b), wid)
 
 
+def _shape_key(name, value):
+    """(type, shape) of a replicated / state / log value as it will be written: what must agree between the ranks."""
+    if isinstance(value, (list, tuple)) and name in ('types', 'type_shapes'):
+        return ('strings', len(value), max([len(str(v).encode('utf-8')) for v in value] or [0]))
+    a = numpy.asarray(value)
+    return (a.dtype.str, a.shape)
+
+
+class _AppendPlan(object):
+    """One frame on its way through `HOOMDTrajectory.append`: `_plan_frame` fills it, `_agree` settles it over the
+    ranks, `_write_frame` carries it out."""
+    __slots__ = ('entries', 'dev', 'host_pp', 'replicated', 'at_count', 'n_local', 'part0', 'ticket', 'compared',
+                 'frame0_equal', 'part_dist', 'n_global', 'declared')
+
+    def __init__(self):
+        self.entries = []       # [path, name, write?] per schema name, in the reference's chunk order
+        self.dev = []           # GPU-resident per-particle attributes: (position in entries, chunk name, DeviceField)
+        self.host_pp = []       # several ranks: per-particle HOST arrays that would be written: (position, chunk, array)
+        self.replicated = []    # (chunk name, shape key) of the replicated values that are set on this rank
+        self.at_count = None    # position of particles/N
+        self.n_local = 0
+        self.part0 = None       # the partition this rank's rows of frame 0 belong to (None: no such comparisons now)
+        self.ticket = None      # staging ticket of the device arrays (None: they leave in fused launches)
+        self.compared = []      # positions in `dev` that were compared on the GPU
+        self.frame0_equal = []  # positions in `entries` elided because they equal THIS rank's rows of frame 0
+        self.part_dist = None
+        self.n_global = 0
+        self.declared = False
+
+
 class HOOMDTrajectory(object):
     """Read and write hoomd pgsd files (hoomd.py:515-940).
 
@@ -358,12 +389,15 @@ class HOOMDTrajectory(object):
         file (`pgsd.fl.PGSDFile` or `pgsd.pypgsd.PGSDFile`): file to access.
 
     Attributes:
-        device_elision: `append` compares GPU-resident per-particle arrays with frame 0 on the GPU and does not
-            write the equal ones.  True (default): an array that differed once is written from then on without a
-            comparison (a moving array costs nothing after the first frame); ``'exact'``: every array is compared in
-            every frame, as host arrays are -- an array that returns to frame 0's values is elided again, at the price
-            of one frame's worth of HBM for the rows of frame 0 and a comparison launch per frame; False:
-            GPU-resident arrays are always written.
+        device_elision: `append` applies the elision rule of hoomd.py:654-694 to GPU-resident per-particle arrays ON
+            THE GPU.  True (default; ``'exact'`` is the same): every array that is set is compared in every frame --
+            with this rank's rows of frame 0 where frame 0 holds the chunk, with the default value where it does
+            not -- and the file is the one host arrays of the same values give, for every input (NaNs, signed zeros,
+            arrays that return to frame 0's values, default-valued arrays); the price is one frame's worth of HBM for
+            the rows of frame 0 and one comparison launch per frame.  ``'once'``: an array that differed once is
+            written from then on without a comparison (a moving array costs nothing after the first frame; an array
+            that returns to frame 0's values is written where the host path would elide it).  False: GPU-resident
+            arrays are always written.
 
     Per-particle attributes of a `Frame` may be numpy arrays, torch GPU tensors or `pgsd.fl.DeviceField` views of
     GPU memory (a column range of a ``Scalar4`` array, a converted or bit-cast element type); `append` writes the
@@ -383,7 +417,8 @@ class HOOMDTrajectory(object):
         self.device_elision = True
         self._dev_ref = {}             # chunk -> GPU tensor: this rank's rows of frame 0 as the chunk stores them
         self._dev_ref_part = None      # the partition (every rank's row count) those rows belong to
-        self._dev_dynamic = set()      # GPU-resident chunks seen to differ from frame 0: not compared any more
+        self._dev_dynamic = set()      # device_elision='once': GPU-resident chunks seen to differ, not compared any more
+        self._default_ref = {}         # (chunk, device) -> GPU tensor: rows of the default value as the chunk stores them
         self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
         self._host_ref = {}            # several ranks: chunk -> this rank's rows of frame 0 (host arrays are compared too)
         self._prefix_names = {}        # reader: prefix -> (nnames when asked, matching chunk names)
@@ -416,7 +451,7 @@ class HOOMDTrajectory(object):
         return 0, 1                     # pgsd.pypgsd.PGSDFile: the pure-Python reader, one rank
 
     def append(self, frame, wait=True):
-        """Append a frame (collective over the ranks of the installed communicator).
+        """Append a frame (collective over the ranks of the file's communicator).
 
         ``wait=False`` seals the frame asynchronously (`pgsd.fl.PGSDFile.end_frame`): call
         ``trajectory.file.wait_packed()`` before changing GPU-resident arrays of the frame and
@@ -433,8 +468,12 @@ class HOOMDTrajectory(object):
           replicated small chunks: ``write_all=False, offset=None`` (hoomd.py:604-630);
         * per-particle arrays: ``write_all=True, offset=part_dist`` (hoomd.py:597-600);
         * ``state/*`` and ``log/*``: ``write_chunk(name, data)`` with default arguments (hoomd.py:634-640);
-        * fields that are ``None`` are not written; host fields that equal the initial frame or the
-          default value are elided as hoomd.py:654-694 describes.
+        * fields that are ``None`` are not written; fields that equal the initial frame, or the default value where
+          frame 0 has no such chunk, are elided as hoomd.py:654-694 describes -- host arrays and GPU-resident arrays
+          alike, by the same rule (``numpy.array_equal``'s equality: a NaN equals nothing, +0.0 equals -0.0).
+
+        Three steps (`_plan_frame`, `_agree`, `_write_frame`): every rank decides what it would write, ONE allgather
+        carries the ranks' row counts and votes, the chunks are written in the reference's order.
 
         Where the sketch cannot be followed literally:
 
@@ -444,125 +483,207 @@ class HOOMDTrajectory(object):
         * the write/skip decision of every chunk is agreed over the ranks (written if any rank needs
           it; a rank without a value contributes the default for its rows), because a chunk write is
           collective; ``particles/N`` is compared as the global count;
-        * with several ranks a per-particle host array is compared with THIS rank's rows of frame 0
-          (`_host_elision_votes`; against the whole of frame 0, as the sketch compares, it could never be equal);
-        * GPU-resident per-particle arrays are compared with frame 0 ON THE GPU (`device_elision`, default on;
-          `_device_elision_votes`): packed by one launch, their packed bytes compared with this rank's rows of frame 0
-          in device memory, the equal ones elided like host arrays -- byte equality, frame 0 itself always written
-          in full (no default-value test), an array that differed once is written from then on without a comparison,
-          a change of the partition ends the comparisons.  ``device_elision = 'exact'``: every array compared in
-          every frame (the host path's decisions); ``False``: always written, consecutive device fields in one fused
-          pack launch each;
+        * with several ranks a per-particle array is compared with THIS rank's rows of frame 0 (against the whole of
+          frame 0, as the sketch compares, it could never be equal), while the partition is the one those rows were
+          written with; after a change of the partition every per-particle array that is set is written;
+        * GPU-resident per-particle arrays are compared ON THE GPU (`device_elision`): packed by one launch, their
+          packed rows compared with this rank's rows of frame 0 (or with rows of the default value) in device memory;
+        * replicated chunks, ``state/*`` and ``log/*`` must have the same shape on every rank (checked in the vote);
         * upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom) follow the
           SPH set in that order when they are set.
         """
-        debug = logger.isEnabledFor(logging.DEBUG)
-        if debug:
+        if logger.isEnabledFor(logging.DEBUG):
             logger.debug('Appending frame to hoomd trajectory: ' + str(self.file))
         frame.validate()
         rank, size = self._comm()
-
-        # the initial frame is the reference for elision.  With several ranks only its REPLICATED part is read:
-        # a per-particle array of frame 0 holds all ranks' rows and can never equal this rank's share (round 2 had
-        # every rank read the whole global frame here -- 2.24 GB each at 8 x 10 M particles -- to find that out)
-        # One rank: a per-particle array of frame 0 is read when (and if) a host array is to be compared with it --
-        # reading all of frame 0 here cost the second append of a 10 M-particle trajectory 250 ms, for arrays that live
-        # on the GPU and are compared there (`_device_elision_votes`) never to be looked at.
-        if self._elision_ref is None and len(self) > 0:
-            if size == 1 and self._initial_frame is not None:
-                self._elision_ref = self._initial_frame
-            else:
-                self._elision_ref = self._read_frame0_replicated()
-                self._elision_lazy = size == 1
-        # ... and so is the set of chunks frame 0 holds (hoomd.py:689-691).  Looked up ONCE, by every rank, for
-        # every name in the same order -- never from inside a comparison only some ranks make: a lookup flushes
-        # whatever is pending, which is collective (a rank whose velocities are all zero would ask alone)
-        if self._frame0_chunks is None and len(self) > 0:
-            self._frame0_chunks = set()
-            for path in ('configuration', 'particles', 'constraints'):
-                container = getattr(frame, path)
-                names = list(container._default_value)
-                if path == 'particles':
-                    names += list(container._extra_default_value)
-                for name in names:
-                    if self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
-                        self._frame0_chunks.add(path + '/' + name)
-
-        # From here on the frame costs ONE collective however many chunks of whatever kind it has: the allgather
-        # below (every rank's row count + its write/skip votes).  With the counts in hand the partition is DECLARED
+        self._elision_reference(frame, size)
+        # From here on the frame costs ONE collective however many chunks of whatever kind it has: the allgather of
+        # `_agree` (every rank's row count + its write/skip votes).  With the counts in hand the partition is DECLARED
         # to the library (pgsd_set_partition), which then places every chunk without an exchange of its own:
         # per-particle chunks by the declared rows (offset='auto'), everything else -- replicated small chunks,
         # state/* and log/* -- has the same size on every rank.  The file is byte-identical to the one the
         # exchanges would produce.  (One rank: nothing to exchange, the batched queue keeps the call pattern.)
         if size == 1 and getattr(self.file, 'frame_exchange', None) is False:
             self.file.frame_exchange = True
+        plan = self._plan_frame(frame, rank, size)
+        self._agree(plan, frame, rank, size)
+        self._write_frame(plan, frame, rank, size, wait)
 
-        # 1. decide locally which chunks to write, then ONE allgather carries every rank's particle count
-        #    (-> part_dist, the MPI_Allgather of benchmark-write.cc:41) and its votes
-        plan = []
-        dev = []        # GPU-resident per-particle attributes: (index in plan, chunk name, DeviceField), schema order
-        host_pp = []    # several ranks: per-particle HOST arrays that would be written: (index in plan, chunk name, array)
-        at_count = None
+    # -- step 0 (once per trajectory): what the elision rule compares with
+    def _elision_reference(self, frame, size):
+        """The initial frame is the reference for elision (hoomd.py:654-694).  With several ranks only its REPLICATED
+        part is read: a per-particle array of frame 0 holds all ranks' rows and can never equal this rank's share
+        (round 2 had every rank read the whole global frame here -- 2.24 GB each at 8 x 10 M particles -- to find
+        that out).  One rank: a per-particle array of frame 0 is read when (and if) a host array is to be compared with
+        it -- reading all of frame 0 here cost the second append of a 10 M-particle trajectory 250 ms, for arrays that
+        live on the GPU and are compared there never to be looked at.
+
+        ... and so is the set of chunks frame 0 holds (hoomd.py:689-691).  Looked up ONCE, by every rank, for every
+        name in the same order -- never from inside a comparison only some ranks make: a lookup flushes whatever is
+        pending, which is collective (a rank whose velocities are all zero would ask alone)."""
+        if len(self) == 0:
+            return
+        if self._elision_ref is None:
+            if size == 1 and self._initial_frame is not None:
+                self._elision_ref = self._initial_frame
+            else:
+                self._elision_ref = self._read_frame0_replicated()
+                self._elision_lazy = size == 1
+        if self._frame0_chunks is None:
+            self._frame0_chunks = set()
+            for path, names in _schema_names(frame):
+                for name in names:
+                    if self.file.chunk_exists(frame=0, name=path + '/' + name, write_all=False):
+                        self._frame0_chunks.add(path + '/' + name)
+
+    # -- step 1: this rank's decisions
+    def _plan_frame(self, frame, rank, size):
+        """What this rank would write: one entry per schema name, in the reference's order."""
+        plan = _AppendPlan()
+        entries = plan.entries
+        dev, host_pp = plan.dev, plan.host_pp
         for path, names in _schema_names(frame):
             values = getattr(frame, path).__dict__
             particles = path == 'particles'
             for name in names:
                 if particles and name == 'N':
-                    # None = "as in frame 0": no count chunk; decided below from the global count otherwise
-                    at_count = len(plan)
-                    plan.append((path, name, frame.particles.N is not None))
+                    # None = "as in frame 0": no count chunk; decided in `_agree` from the global count otherwise
+                    plan.at_count = len(entries)
+                    entries.append([path, name, frame.particles.N is not None])
                     continue
                 value = values.get(name)
                 if value is None and name == 'box':
                     value = values.get('_box')              # (the one attribute kept behind a property)
                 if value is None:
-                    plan.append((path, name, False))        # most of the schema, most of the time: not set
-                elif particles and _is_device(value) and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
+                    entries.append([path, name, False])     # most of the schema, most of the time: not set
+                    continue
+                per_particle = particles and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA)
+                if per_particle and _is_device(value):
                     dt, _ = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
                     field = value if isinstance(value, fl.DeviceField) else fl.DeviceField.from_tensor(value, out_dtype=dt)
-                    dev.append((len(plan), path + '/' + name, field))
-                    plan.append((path, name, True))
+                    dev.append((len(entries), path + '/' + name, field))
+                    entries.append([path, name, True])
+                    continue
+                write = self._should_write(path, name, frame, None)
+                if per_particle:
+                    if write and size > 1:
+                        host_pp.append((len(entries), path + '/' + name, value))
                 else:
-                    write = self._should_write(path, name, frame, None)
-                    if write and size > 1 and path == 'particles' and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA):
-                        host_pp.append((len(plan), path + '/' + name, value))
-                    plan.append((path, name, write))
-        n_local = int(frame.particles.N) if frame.particles.N is not None else 0
-        part0 = self._frame0_partition(frame, dev or host_pp, rank, size, n_local)
-        self._host_elision_votes(host_pp, plan, part0, rank, n_local)
-        ticket, compared = self._device_elision_votes(dev, plan, part0, rank, n_local)
+                    plan.replicated.append((path + '/' + name, _shape_key(name, value)))
+                entries.append([path, name, write])
+        plan.n_local = int(frame.particles.N) if frame.particles.N is not None else 0
+        plan.part0 = self._frame0_partition(frame, dev or host_pp, rank, size, plan.n_local)
+        self._host_row_votes(plan, rank)
+        self._device_votes(plan, rank)
+        return plan
+
+    # -- step 2: the frame's ONE collective
+    def _agree(self, plan, frame, rank, size):
+        """One allgather carries every rank's particle count (-> part_dist, the MPI_Allgather of
+        benchmark-write.cc:41), a digest of the shapes of its replicated / state / log chunks, and two bits per plan
+        entry: "write" and "elided only because it equals THIS rank's rows of frame 0".  Everything decided from here
+        on rests on replicated data, so every rank decides alike."""
+        entries = plan.entries
+        n_local = plan.n_local
         if frame.part_dist is not None:
             part_dist = numpy.asarray(frame.part_dist, dtype=numpy.uint64)
             if part_dist.shape[0] != size:
                 raise ValueError("part_dist must have one entry per rank")
         else:
             part_dist = numpy.array([n_local], dtype=numpy.uint64)
+        rows_equal = numpy.zeros(len(entries), dtype=bool)      # any rank: elided against its rows of frame 0
+        for at in plan.frame0_equal:
+            rows_equal[at] = True
         if size > 1:
-            mine = numpy.zeros(8 + len(plan), dtype=numpy.uint8)
+            mine = numpy.zeros(16 + len(entries), dtype=numpy.uint8)
             mine[:8] = numpy.array([n_local], dtype=numpy.uint64).view(numpy.uint8)
-            mine[8:] = [1 if w else 0 for _, _, w in plan]
+            digest = hashlib.blake2b(repr(plan.replicated + [('state/' + k, _shape_key(k, v)) for k, v in frame.state.items()]
+                                          + [('log/' + k, _shape_key(k, v)) for k, v in frame.log.items()]).encode(),
+                                     digest_size=8).digest()
+            mine[8:16] = numpy.frombuffer(digest, dtype=numpy.uint8)
+            mine[16:] = [(1 if e[2] else 0) | (2 if rows_equal[at] else 0) for at, e in enumerate(entries)]
             allb = self.file.allgather(mine)
             if frame.part_dist is None:
                 part_dist = numpy.ascontiguousarray(allb[:, :8]).view(numpy.uint64).reshape(size)
-            agreed = allb[:, 8:].max(axis=0)
-            plan = [(p, n, bool(a)) for (p, n, _), a in zip(plan, agreed)]
-        n_global = int(part_dist.sum())
-        if at_count is not None and plan[at_count][2]:
-            plan[at_count] = ('particles', 'N', self._should_write('particles', 'N', frame, n_global))
-        self._elision_outcome(dev, host_pp, plan, compared, part0, part_dist)
-        declared = size > 1 and hasattr(self.file, 'set_partition')
-        if declared:
-            if int(part_dist[rank]) != n_local:
-                raise ValueError("part_dist[%d] = %d but this rank holds %d particles" % (rank, int(part_dist[rank]), n_local))
-            self.file.set_partition(part_dist)
-        particle_offset = 'auto' if declared else part_dist
+            if (allb[:, 8:16] != allb[0, 8:16]).any():
+                # placed without an exchange (declared partition), such chunks would put different offsets into each
+                # rank's replicated index: every rank sees the same vector, every rank stops here
+                raise ValueError("replicated chunks (configuration/*, types, constraints/*, state/*, log/*) must be set "
+                                 "on every rank with the same shape and type: the ranks differ")
+            bits = allb[:, 16:]
+            for e, w in zip(entries, (bits & 1).max(axis=0)):
+                e[2] = bool(w)
+            rows_equal = (bits & 2).max(axis=0).astype(bool)
+        plan.part_dist = part_dist
+        plan.n_global = int(part_dist.sum())
+        if plan.at_count is not None and entries[plan.at_count][2]:
+            entries[plan.at_count][2] = self._should_write('particles', 'N', frame, plan.n_global)
+        self._partition_bookkeeping(plan, rows_equal, size)
+        plan.declared = size > 1 and hasattr(self.file, 'set_partition')
+        if plan.declared and int(part_dist[rank]) != n_local:
+            raise ValueError("part_dist[%d] = %d but this rank holds %d particles" % (rank, int(part_dist[rank]), n_local))
 
-        # 2. write, in the reference's chunk order; device fields go out in one fused launch
+    def _partition_bookkeeping(self, plan, rows_equal, size):
+        """Comparisons with this rank's rows of frame 0 hold while the partition is the one those rows were written
+        with.  Decided from the gathered partition and the gathered "equal to my rows of frame 0" bits alone --
+        replicated data (the override used to hang on a rank-local condition, so that one rank placed a
+        chunk the others did not)."""
+        part = tuple(int(x) for x in plan.part_dist)
+        n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
+        fits = len(self) == 0 or (n0 is not None and int(n0) == sum(part))     # frame 0 has that many particles
+        if size == 1:
+            # one rank: "my rows of frame 0" are the whole of frame 0 -- comparable whenever the counts agree, in
+            # whatever frame (`_frame0_partition`), exactly as host arrays are compared (`_should_write`)
+            if self._dev_ref_part is None and fits:
+                self._dev_ref_part = part
+        elif not self._dev_off:
+            if self._dev_ref_part is None:
+                # frame 0 being written, or the first frame appended to an existing file: the rows of frame 0 kept /
+                # read from now on are those of THIS partition
+                if fits:
+                    self._dev_ref_part = part
+                else:
+                    self._dev_off = True
+            elif part != self._dev_ref_part:
+                # particles moved between the ranks (or their number changed): whatever was compared was compared
+                # with other particles' rows.  Every per-particle array that some rank elided on those grounds is
+                # written, and every array that is set from now on
+                self._dev_off = True
+                for at, e in enumerate(plan.entries):
+                    if rows_equal[at]:
+                        e[2] = True
+        if self._dev_off:
+            self._dev_ref.clear()
+            self._host_ref.clear()
+            return
+        if self.device_elision == 'once':
+            for k in plan.compared:
+                at, chunk, _ = plan.dev[k]
+                if plan.entries[at][2]:
+                    self._dev_dynamic.add(chunk)        # differs (on some rank): a moving array, not compared again
+                    self._dev_ref.pop(chunk, None)
+
+    # -- step 3: the chunks, in the reference's order
+    def _write_frame(self, plan, frame, rank, size, wait):
+        debug = logger.isEnabledFor(logging.DEBUG)
+        part_dist, n_local, n_global = plan.part_dist, plan.n_local, plan.n_global
+        if plan.declared:
+            self.file.set_partition(part_dist)
+        particle_offset = 'auto' if plan.declared else part_dist
+        ticket = plan.ticket
+        if ticket is not None and len(self) == 0 and self._dev_ref_part is not None:
+            # frame 0: the packed rows of what is written stay in HBM for the comparisons to come (a device-to-device
+            # copy behind the pack)
+            sizes = [int(f.N) * int(f.M) * f.out_dtype.itemsize if plan.entries[at][2] else None for at, _, f in plan.dev]
+            for (_, chunk, _), ref in zip(plan.dev, self.file.copy_staged(ticket, 0, sizes)):
+                if ref is not None:
+                    self._dev_ref[chunk] = ref
         device_fields = []      # not staged: consecutive GPU-resident fields leave in one fused launch
-        staged_run = []         # staged (one launch for the whole frame, above): consecutive chunk numbers of the ticket
-        dev_at = dict((at, (k, field)) for k, (at, _, field) in enumerate(dev)) if dev else {}
-        for at in [i for i, entry in enumerate(plan) if entry[2]]:
-            path, name, _ = plan[at]
+        staged_run = []         # staged (one launch for the whole frame): consecutive chunk numbers of the ticket
+        dev_at = dict((at, (k, field)) for k, (at, _, field) in enumerate(plan.dev)) if plan.dev else {}
+        for at, (path, name, write) in enumerate(plan.entries):
+            if not write:
+                continue
             container = getattr(frame, path)
             data = getattr(container, name)
             chunk = path + '/' + name
@@ -584,16 +705,12 @@ class HOOMDTrajectory(object):
                     default = container._default_value.get(name, container._extra_default_value.get(name))
                     data = numpy.empty([n_local] + ([M] if M > 1 else []), dtype=dt)
                     data[...] = default
-                if device_fields:
-                    self._flush_device_fields(device_fields, particle_offset, rank)
-                if staged_run:
-                    self._flush_staged(ticket, staged_run, particle_offset, rank)
+                self._flush_device_fields(device_fields, particle_offset, rank)
+                self._flush_staged(ticket, staged_run, particle_offset, rank)
                 self.file.write_chunk(chunk, data, particle_offset, rank, True)
                 continue
-            if device_fields:
-                self._flush_device_fields(device_fields, particle_offset, rank)
-            if staged_run:
-                self._flush_staged(ticket, staged_run, particle_offset, rank)
+            self._flush_device_fields(device_fields, particle_offset, rank)
+            self._flush_staged(ticket, staged_run, particle_offset, rank)
             # replicated small chunks (hoomd.py:604-630)
             if name == 'N':
                 count = n_global if path == 'particles' else int(container.N)
@@ -620,7 +737,7 @@ class HOOMDTrajectory(object):
             self.file.write_chunk('log/' + log, data)
 
         self.file.end_frame(wait=wait)
-        if declared:
+        if plan.declared:
             self.file.set_partition(None)       # the declaration was this frame's
 
     def _flush_staged(self, ticket, run, part_dist, rank):
@@ -630,7 +747,7 @@ class HOOMDTrajectory(object):
 
     def _frame0_partition(self, frame, wanted, rank, size, n_local):
         """The partition (every rank's row count) for which this rank's rows of frame 0 are, or can be, at hand -- or
-        None when per-particle arrays cannot be compared with frame 0 in this frame: nothing to compare, frame 0
+        None when per-particle arrays cannot be compared with frame 0's rows in this frame: nothing to compare, frame 0
         itself, the comparisons ended (`_dev_off`), a partition that differs from the one the rows were taken for,
         or one that is not known before the frame's exchange (no `Frame.part_dist`, several ranks, first frame
         appended to an existing file: the comparisons then start with the next frame)."""
@@ -648,16 +765,16 @@ class HOOMDTrajectory(object):
                 return None
             part = given
         elif given is not None and given != part:
-            return None                     # (`_elision_outcome` sees the change and ends the comparisons)
+            return None                     # (`_partition_bookkeeping` sees the change and ends the comparisons)
         if len(part) != size or part[rank] != n_local:
             return None
         return part
 
     def _read_frame0_rows(self, chunk, row0, n, device):
         """This rank's rows ``[row0, row0 + n)`` of a per-particle chunk of frame 0, as a numpy array or a GPU tensor.
-        A LOCAL read (`PGSDFile.local_reads`): these are rows this rank wrote itself in this session, or rows of a
-        file that was complete when it was opened -- and which arrays a rank compares need not be the same on every
-        rank, so the read must not be a collective."""
+        A LOCAL read (`PGSDFile.local_reads`, lookup included): these are rows this rank wrote itself in this session,
+        or rows of a file that was complete when it was opened -- and which arrays a rank compares need not be the
+        same on every rank, so the read must not be a collective."""
         f = self.file
         before = f.local_reads
         f.local_reads = True
@@ -668,104 +785,97 @@ class HOOMDTrajectory(object):
         finally:
             f.local_reads = before
 
-    def _host_elision_votes(self, host_pp, plan, part0, rank, n_local):
+    def _host_row_votes(self, plan, rank):
         """Several ranks: a per-particle HOST array is compared with THIS RANK'S rows of frame 0 (read from the file
         when first needed, ``numpy.array_equal`` as on one rank); equal rows vote "skip".  (Compared with the whole of
         frame 0 -- every rank's rows -- as the sketch has it, hoomd.py:673-687, an array could never be equal.)"""
-        if not host_pp or part0 is None:
+        if not plan.host_pp or plan.part0 is None:
             return
         frame0 = self._frame0_chunks or ()
-        row0 = sum(part0[:rank])
-        for at, chunk, data in host_pp:
+        row0 = sum(plan.part0[:rank])
+        for at, chunk, data in plan.host_pp:
             if chunk not in frame0:
                 continue
             ref = self._host_ref.get(chunk)
             if ref is None:
-                ref = self._read_frame0_rows(chunk, row0, n_local, False)
+                ref = self._read_frame0_rows(chunk, row0, plan.n_local, False)
                 self._host_ref[chunk] = ref
             if _equal(ref, data):
                 logger.debug('skipping data chunk, this rank\'s rows match frame 0: ' + chunk)
-                plan[at] = (plan[at][0], plan[at][1], False)
+                plan.entries[at][2] = False
+                plan.frame0_equal.append(at)
 
-    def _device_elision_votes(self, dev, plan, part0, rank, n_local):
-        """The elision test of hoomd.py:654-694 for GPU-resident per-particle arrays, on the GPU.
+    def _default_rows(self, chunk, field, device):
+        """Rows of the schema's default value for ``chunk`` as the chunk stores them, in device memory: what "equals
+        the default" is tested against (hoomd.py:692-693).  4096 rows stand for any number (the comparison lets a
+        short reference repeat); fewer rows than that get exactly as many."""
+        key = (chunk, device)
+        ref = self._default_ref.get(key)
+        if ref is None:
+            import torch
+            name = chunk.split('/', 1)[1]
+            default = ParticleData._default_value.get(name, ParticleData._extra_default_value.get(name))
+            rows = numpy.empty((4096, int(field.M)), dtype=field.out_dtype)
+            rows[...] = default
+            ref = torch.from_numpy(rows.view(numpy.uint8).reshape(-1)).to(torch.device('cuda', device))
+            self._default_ref[key] = ref
+        want = int(field.N) * int(field.M) * field.out_dtype.itemsize
+        return ref if want >= ref.numel() else ref[:want]
 
-        All of the frame's GPU-resident arrays are packed by ONE launch into staging (`stage_chunks`); the packed
-        bytes of those that have equalled frame 0 so far are compared with this rank's rows of frame 0 in device
-        memory (`compare_staged`: one kernel, one stream wait) and the equal ones vote "skip" in ``plan``.  Frame 0's
-        rows come from the staging of frame 0 itself when this trajectory wrote it (`copy_staged`: a device-to-device
-        copy), from the file otherwise (`read_chunk_device`, once per array).  An array that differed once is not
-        compared again; a change of the partition ends the comparisons (frame 0's rows are other particles' then).
-        Byte equality: an array holding NaNs is elided when the bits match (numpy.array_equal would write it), +0.0 /
-        -0.0 differ (numpy would elide) -- either way the reader gets the frame's bits.
+    def _device_votes(self, plan, rank):
+        """The elision rule of hoomd.py:654-694 for GPU-resident per-particle arrays, decided on the GPU exactly as
+        `_should_write` decides it for host arrays: a chunk frame 0 holds is compared with this rank's rows of frame 0
+        (equal: skip), a chunk frame 0 does not hold -- or frame 0 itself -- with rows of the default value (equal:
+        skip).  Equality is ``numpy.array_equal``'s (`PGSDFile.compare_staged`): the file is the one host arrays of
+        the same values give.
 
-        Returns ``(ticket, compared)``: the staging ticket (None: nothing staged, the fields leave in fused launches as
-        before) and the positions in ``dev`` that were compared."""
+        All of the frame's GPU-resident arrays are packed by ONE launch into staging (`stage_chunks`) and compared by
+        one more (`compare_staged`: one stream wait).  Frame 0's rows come from the staging of frame 0 itself when
+        this trajectory wrote it (`copy_staged` in `_write_frame`: a device-to-device copy), from the file otherwise
+        (`read_chunk_device`, once per array).  ``device_elision = 'once'``: an array that differed once is written
+        from then on without a comparison; ``False``: no comparisons, every array that is set is written."""
         f = self.file
-        if not dev or not self.device_elision or self._dev_off or not hasattr(f, 'compare_staged'):
-            return None, []
-        fields = [(chunk, field) for _, chunk, field in dev]
-        if len(self) == 0:
-            # frame 0 itself: written in full; its packed rows stay in HBM for the comparisons to come
-            ticket = f.stage_chunks(fields)
-            sizes = [int(field.N) * int(field.M) * field.out_dtype.itemsize for _, field in fields]
-            self._dev_ref = dict(zip((c for c, _ in fields), f.copy_staged(ticket, 0, sizes)))
-            return ticket, []
-        if part0 is None:
-            return None, []
-        frame0 = self._frame0_chunks or ()
-        candidates = [k for k, (_, chunk, _) in enumerate(dev) if chunk not in self._dev_dynamic and chunk in frame0]
-        if not candidates:
-            return None, []
-        row0 = sum(part0[:rank])
-        ticket = f.stage_chunks(fields)
+        dev = plan.dev
+        if not dev or not self.device_elision or not hasattr(f, 'compare_staged'):
+            return
+        frame0 = (self._frame0_chunks or ()) if len(self) > 0 else ()
+        part0 = plan.part0
         refs = [None] * len(dev)
-        for k in candidates:
-            _, chunk, field = dev[k]
-            ref = self._dev_ref.get(chunk)
-            if ref is None:
-                ref = self._read_frame0_rows(chunk, row0, n_local, True)
-                self._dev_ref[chunk] = ref
-            if ref.numel() * ref.element_size() == int(field.N) * int(field.M) * field.out_dtype.itemsize:
-                refs[k] = ref
-        equal = f.compare_staged(ticket, 0, refs)
-        for k in candidates:
-            at = dev[k][0]
-            plan[at] = (plan[at][0], plan[at][1], not equal[k])
-        return ticket, candidates
-
-    def _elision_outcome(self, dev, host_pp, plan, compared, part0, part_dist):
-        """After the ranks agreed on ``plan``: book-keeping of the comparisons with this rank's rows of frame 0
-        (`_host_elision_votes`, `_device_elision_votes`); identical on every rank."""
-        if self._dev_off:
-            return
-        part = tuple(int(x) for x in part_dist)
-        if self._dev_ref_part is None:
-            # frame 0 being written, or the first frame appended to an existing file: the rows of frame 0 kept / read
-            # from now on are those of THIS partition -- if frame 0 has that many particles at all
-            n0 = self._elision_ref.particles.N if self._elision_ref is not None else None
-            if len(self) > 0 and (n0 is None or int(n0) != sum(part)):
-                self._dev_off = True
+        kinds = [None] * len(dev)                   # 'rows': against frame 0's rows; 'default': against the default
+        device = None
+        for k, (_, chunk, field) in enumerate(dev):
+            if chunk in self._dev_dynamic:
+                continue
+            if chunk in frame0:
+                if part0 is not None and not self._dev_off:
+                    kinds[k] = 'rows'
             else:
-                self._dev_ref_part = part
-        elif part != self._dev_ref_part:
-            # particles moved between the ranks (or their number changed): whatever was compared was compared with
-            # other particles' rows.  Every per-particle array that is set is written, now and from now on
-            self._dev_off = True
-            if part0 is not None:
-                for at, _, _ in list(dev) + list(host_pp):
-                    plan[at] = (plan[at][0], plan[at][1], True)
-        if self._dev_off:
-            self._dev_ref.clear()
-            self._host_ref.clear()
+                kinds[k] = 'default'
+        if not any(kinds):
             return
-        if self.device_elision == 'exact':
-            return                                      # every array is compared in every frame, like host arrays
-        for k in compared:
-            at, chunk, _ = dev[k]
-            if plan[at][2]:
-                self._dev_dynamic.add(chunk)            # differs from frame 0 (on some rank): a moving array
-                self._dev_ref.pop(chunk, None)
+        ticket = f.stage_chunks([(chunk, field) for _, chunk, field in dev])
+        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else 0
+        row0 = sum(part0[:rank]) if part0 is not None else 0
+        for k, (_, chunk, field) in enumerate(dev):
+            if kinds[k] == 'default':
+                refs[k] = self._default_rows(chunk, field, device)
+            elif kinds[k] == 'rows':
+                ref = self._dev_ref.get(chunk)
+                if ref is None:
+                    ref = self._read_frame0_rows(chunk, row0, plan.n_local, True)
+                    self._dev_ref[chunk] = ref
+                if ref.numel() * ref.element_size() == int(field.N) * int(field.M) * field.out_dtype.itemsize:
+                    refs[k] = ref
+        equal = f.compare_staged(ticket, 0, refs)
+        for k, (at, chunk, _) in enumerate(dev):
+            if refs[k] is None:
+                continue
+            plan.compared.append(k)
+            if equal[k]:
+                plan.entries[at][2] = False
+                if kinds[k] == 'rows':
+                    plan.frame0_equal.append(at)
+        plan.ticket = ticket
 
     def _flush_device_fields(self, device_fields, part_dist, rank):
         if device_fields:

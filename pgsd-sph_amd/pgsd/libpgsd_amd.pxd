@@ -181,7 +181,7 @@ cdef extern from "pgsd.h" nogil:
     int pgsd_write_staged_chunks(pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
                                  uint64_t N_global, uint64_t offset_rows)
     int pgsd_compare_staged_chunks(pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
-                                   const void* const* ref, uint8_t* equal)
+                                   const void* const* ref, const uint64_t* ref_bytes, uint8_t* equal)
     int pgsd_copy_staged_chunks(pgsd_handle* handle, uint64_t ticket, uint32_t first, uint32_t count,
                                 void* const* dst)
     int pgsd_end_frame_async(pgsd_handle* handle)

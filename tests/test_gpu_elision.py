@@ -111,38 +111,58 @@ def _trajectory(rng, N, frames):
 
 @pytest.mark.parametrize("N", [777, 200_000])
 def test_append_elides_static_gpu_arrays_like_host_arrays(N, tmp_path):
-    """The same frames from GPU-resident and from host arrays: identical files, except that an array that differed once
-    (the density, frame 2) is written from then on by the device path -- so the data here are chosen for identical
-    files up to frame 2 and identical CONTENT after."""
+    """The same frames from GPU-resident and from host arrays: identical files -- the density, which differs in frame 2
+    only, is written there and elided again afterwards, on both paths."""
     import pgsd.fl as fl
     import pgsd.hoomd as hoomd
     frames = _trajectory(np.random.default_rng(N), N, 5)
     a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
     keep = []
-    for path, on_gpu, upto in ((a, True, 2), (b, False, 2)):
+    for path, on_gpu in ((a, True), (b, False)):
         with hoomd.open(path, "w") as t:
-            for args in frames[:upto]:
+            for args in frames:
                 t.append(_frame(hoomd, fl, *args, on_gpu, keep))
             if on_gpu:
-                assert t._dev_dynamic == {"particles/position", "particles/velocity"}
-                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
+                assert not t._dev_dynamic and not t._dev_off
+                assert set(t._dev_ref) == {"particles/" + n for n in ("position", "typeid", "velocity", "mass", "density")}
     with open(a, "rb") as fa, open(b, "rb") as fb:
         assert fa.read() == fb.read()
-    with hoomd.open(a, "w") as t:
-        for args in frames:
-            t.append(_frame(hoomd, fl, *args, True, keep))
-        assert "particles/density" in t._dev_dynamic and not t._dev_off
     with hoomd.open(a, "r") as t:
         f = t.file
         assert [f.chunk_exists(k, "particles/typeid") for k in range(5)] == [True, False, False, False, False]
         assert [f.chunk_exists(k, "particles/mass") for k in range(5)] == [True, False, False, False, False]
-        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, True, True]
+        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, False, False]
         assert all(f.chunk_exists(k, "particles/position") for k in range(5))
         for k, (step, pos, tid, mass, vel, dens) in enumerate(frames):
             fr = t[k]
             assert fr.configuration.step == step
             for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
                 assert getattr(fr.particles, name).tobytes() == want.tobytes(), (k, name)
+
+
+def test_once_mode_stops_comparing_an_array_that_differed(tmp_path):
+    """`device_elision = 'once'` (the default of round 3): an array that differed from frame 0 once is written from
+    then on without a comparison -- the density that differs in frame 2 only is written in frames 3 and 4 too, where
+    the host path (and the default mode) elide it; the reader gets the same values either way."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    frames = _trajectory(np.random.default_rng(5), 3000, 5)
+    path, keep = str(tmp_path / "gpu.gsd"), []
+    with hoomd.open(path, "w") as t:
+        t.device_elision = 'once'
+        for k, args in enumerate(frames):
+            t.append(_frame(hoomd, fl, *args, True, keep))
+            if k == 1:
+                assert t._dev_dynamic == {"particles/position", "particles/velocity"}
+                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
+        assert "particles/density" in t._dev_dynamic and not t._dev_off
+    with hoomd.open(path, "r") as t:
+        f = t.file
+        assert [f.chunk_exists(k, "particles/typeid") for k in range(5)] == [True, False, False, False, False]
+        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, True, True]
+        for k, (step, pos, tid, mass, vel, dens) in enumerate(frames):
+            for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
+                assert getattr(t[k].particles, name).tobytes() == want.tobytes(), (k, name)
 
 
 def test_append_device_elision_off_writes_everything(tmp_path):
@@ -171,36 +191,44 @@ def test_append_to_an_existing_file_compares_with_rows_read_from_frame_0(tmp_pat
             t.append(_frame(hoomd, fl, *frames[0], on_gpu, keep))
         with hoomd.open(path, "r+") as t:
             t.append(_frame(hoomd, fl, *frames[1], on_gpu, keep))
-            if on_gpu:
-                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
+            if on_gpu:      # every array was compared, each with rows read from the file
+                assert set(t._dev_ref) == {"particles/" + n for n in ("position", "typeid", "velocity", "mass", "density")}
     with open(a, "rb") as fa, open(b, "rb") as fb:
         assert fa.read() == fb.read()
 
 
-def test_particle_count_change_ends_the_comparisons(tmp_path):
+def test_particle_count_change_and_back_follows_the_host_path(tmp_path):
+    """One rank: while the particle count differs from frame 0's nothing can equal frame 0 -- everything is written;
+    when it is frame 0's count again the arrays are compared again, as `numpy.array_equal` compares host arrays of
+    equal shape (hoomd.py:679-682).  Same file as the host path."""
     import pgsd.fl as fl
     import pgsd.hoomd as hoomd
     rng = np.random.default_rng(2)
     f3 = _trajectory(rng, 400, 2)
     other = _trajectory(rng, 300, 1)[0]
-    path, keep = str(tmp_path / "t.gsd"), []
-    with hoomd.open(path, "w") as t:
-        t.append(_frame(hoomd, fl, *f3[0], True, keep))
-        t.append(_frame(hoomd, fl, *f3[1], True, keep))
-        t.append(_frame(hoomd, fl, 99, *other[1:], True, keep))         # 300 particles
-        assert t._dev_off and not t._dev_ref
-        back = (100,) + f3[0][1:]
-        t.append(_frame(hoomd, fl, *back, True, keep))                   # 400 again, equal to frame 0: written all the same
-    with hoomd.open(path, "r") as t:
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    keep = []
+    for path, on_gpu in ((a, True), (b, False)):
+        with hoomd.open(path, "w") as t:
+            t.append(_frame(hoomd, fl, *f3[0], on_gpu, keep))
+            t.append(_frame(hoomd, fl, *f3[1], on_gpu, keep))
+            t.append(_frame(hoomd, fl, 99, *other[1:], on_gpu, keep))       # 300 particles
+            back = (100,) + f3[0][1:]
+            t.append(_frame(hoomd, fl, *back, on_gpu, keep))                 # 400 again, equal to frame 0: elided again
+            if on_gpu:
+                assert not t._dev_off
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with hoomd.open(a, "r") as t:
         ex = [t.file.chunk_exists(k, "particles/typeid") for k in range(4)]
-        assert ex == [True, False, True, True]
+        assert ex == [True, False, True, False]
         assert t[2].particles.N == 300 and t[3].particles.typeid.tobytes() == f3[0][2].tobytes()
 
 
 # ---------------------------------------------------------------- two ranks: the outcome is agreed
 def _one_sided_frames():
     """Frame 1: type id, mass, image and density as in frame 0 except ONE density value in the last row (the last
-    rank's); frame 2: everything as in frame 0 again -- the density was written once and is written from then on."""
+    rank's); frame 2: everything as in frame 0 again -- the density is elided again."""
     import test_hoomd_append_oracle as A
     f0 = A.global_frames()[0]
     n = f0["n"]
@@ -249,15 +277,15 @@ def _append_rank(rank, P, shm, path, q):
 
 
 def test_two_ranks_agree_on_what_is_elided(tmp_path):
-    """A difference in ONE rank's rows: both ranks write the chunk (the vote rides in the frame's allgather), both
-    stop comparing it, and the file is the model's (`device_votes` in tests/test_hoomd_append_oracle.py)."""
+    """A difference in ONE rank's rows: both ranks write the chunk (the vote rides in the frame's allgather), and the
+    file is the model's (tests/test_hoomd_append_oracle.py: GPU-resident arrays are decided like host arrays)."""
     import multiprocessing as mp
     import uuid
     import test_hoomd_append_oracle as A
     P = 2
     ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
     written = A.expected_file(ref, P, device=True, frames=_one_sided_frames())
-    assert "particles/density" in written[1] and "particles/density" in written[2]
+    assert "particles/density" in written[1] and "particles/density" not in written[2]
     assert "particles/typeid" not in written[1] and "particles/mass" not in written[2]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -269,7 +297,7 @@ def test_two_ranks_agree_on_what_is_elided(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert all(msg == "ok" for _, msg, _ in results), results
-    assert results[0][2] == results[1][2] == ["particles/density", "particles/position"]
+    assert results[0][2] == results[1][2] == []               # nothing is taken off the comparisons
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
 
@@ -337,7 +365,7 @@ def test_two_ranks_reopened_file_reads_each_ranks_rows_of_frame_0(explicit, tmp_
     for p in procs:
         p.join(timeout=60)
     assert all(msg == "ok" for _, msg, _ in results), results
-    assert results[0][2] == results[1][2] == ["particles/mass", "particles/typeid"]    # the density moved in frame 2
+    assert results[0][2] == results[1][2] == ["particles/" + n for n in ("density", "mass", "position", "typeid", "velocity")]
     frames = _trajectory(np.random.default_rng(77), 1000, 3)
     with hoomd.open(path, "r") as t:
         f = t.file
@@ -411,8 +439,8 @@ def _random_rank(rank, P, shm, path, seed, q):
 @pytest.mark.parametrize("seed,P", [(1, 2), (8, 2), (9, 3), (13, 2), (23, 3), (4, 3)])
 def test_random_multi_rank_device_trajectories_match_the_model(seed, P, tmp_path):
     """The random trajectories of tests/test_hoomd_append_oracle.py with every per-particle array in HBM, two or three
-    ranks sharing the GPU: the file is the model's (`device_votes`: byte equality on every rank, an array that
-    differed once written from then on, the comparisons ending with a change of the partition)."""
+    ranks sharing the GPU: the file is the model's -- GPU-resident arrays are decided exactly as host arrays are
+    (every rank's rows against its rows of frame 0, the comparisons ending with a change of the partition)."""
     import multiprocessing as mp
     import uuid
     import test_hoomd_append_oracle as A
@@ -432,30 +460,83 @@ def test_random_multi_rank_device_trajectories_match_the_model(seed, P, tmp_path
         assert a.read() == b.read()
 
 
-def test_byte_equality_nan_and_signed_zero(tmp_path):
-    """The GPU comparison is of BYTES: a static array holding NaNs is elided (numpy.array_equal would write it:
-    NaN != NaN), +0.0 against -0.0 is written (numpy would elide).  Either way the reader gets the frame's bits."""
+def test_equality_is_numpys_nan_signed_zero_and_defaults(tmp_path):
+    """The GPU comparison decides as `numpy.array_equal` does (hoomd.py:679-682): a static array holding a NaN is
+    WRITTEN (NaN != NaN), +0.0 against -0.0 is elided; and the default-value half of the rule: an array that equals the
+    default everywhere is not written when frame 0 has no such chunk -- in frame 0 itself too.  Files identical to the
+    host path's."""
     import pgsd.hoomd as hoomd
-    N = 300
+    N = 9000
     dens = np.linspace(1, 2, N).astype(np.float32)
     dens[7] = np.nan
     energy0 = np.full(N, 3.0, np.float32)
     energy0[5] = 0.0
     energy1 = energy0.copy()
     energy1[5] = -0.0
-    path = str(tmp_path / "t.gsd")
-    with hoomd.open(path, "w") as t:
-        for k, energy in enumerate((energy0, energy1)):
-            fr = hoomd.Frame()
-            fr.configuration.step = k
-            fr.particles.N = N
-            fr.particles.density = dev(dens)
-            fr.particles.energy = dev(energy)
-            t.append(fr)
-    with hoomd.open(path, "r") as t:
-        assert not t.file.chunk_exists(1, "particles/density") and t.file.chunk_exists(1, "particles/energy")
+    body = np.full(N, -1, np.int32)                              # the default
+    vel0 = np.zeros((N, 3), np.float32)                         # the default
+    vel0[N - 1, 2] = -0.0                                       # ... by value
+    vel2 = vel0.copy()
+    vel2[N // 2, 1] = 1e-30
+    a, b = str(tmp_path / "gpu.gsd"), str(tmp_path / "host.gsd")
+    for path, put in ((a, dev), (b, lambda x: x)):
+        with hoomd.open(path, "w") as t:
+            for k, (energy, vel) in enumerate(((energy0, vel0), (energy1, vel0), (energy1, vel2))):
+                fr = hoomd.Frame()
+                fr.configuration.step = k
+                fr.particles.N = N
+                fr.particles.density = put(dens)
+                fr.particles.energy = put(energy)
+                fr.particles.body = put(body)
+                fr.particles.velocity = put(vel)
+                t.append(fr)
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with hoomd.open(a, "r") as t:
+        ex = lambda name: [t.file.chunk_exists(k, "particles/" + name) for k in range(3)]
+        assert ex("density") == [True, True, True] and ex("energy") == [True, False, False]
+        assert ex("body") == [False, False, False] and ex("velocity") == [False, False, True]
         assert t[1].particles.density.tobytes() == dens.tobytes()
-        assert t[1].particles.energy.tobytes() == energy1.tobytes() != energy0.tobytes()
+        assert t[2].particles.velocity.tobytes() == vel2.tobytes()
+
+
+def test_compare_staged_short_references_repeat(tmp_gsd):
+    """`compare_staged` with a reference shorter than the chunk: the reference repeats -- 4096 rows of a value stand for
+    any number of rows; 16-byte vectors that straddle rows (12-byte rows), a difference in the very last row, in a row
+    beyond the first period, NaN rows (never equal), unaligned chunk sizes."""
+    import pgsd.fl as fl
+    N = 100_003
+    row = np.array([0.5, -2.0, 7.25], np.float32)
+    pos = np.zeros((N, 4), np.float32)
+    pos[:, :3] = row
+    ids = np.full(N, 7, np.int32)
+    dpos, dids = dev(pos), dev(ids)
+    ref_rows = torch.from_numpy(np.tile(row, (4096, 1)).view(np.uint8).reshape(-1)).cuda()
+    ref_ids = torch.from_numpy(np.full(4096, 7, np.int32).view(np.uint8)).cuda()
+    with fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4]) as f:
+        f.frame_exchange = True
+
+        def same():
+            t = f.stage_chunks([("particles/position", fl.DeviceField.from_tensor(dpos, columns=(0, 3))),
+                                ("particles/body", dids)])
+            out = f.compare_staged(t, 0, [ref_rows, ref_ids])
+            f.end_frame()
+            return out
+        assert same() == [True, True]
+        dpos[N - 1, 2] = 7.5
+        assert same() == [False, True]
+        dpos[N - 1, 2] = 7.25
+        dids[50_000] = 8
+        assert same() == [True, False]
+        dids[50_000] = 7
+        dpos[4097, 0] = float("nan")
+        ref_nan = ref_rows.clone().view(torch.float32)
+        ref_nan[4097 % 4096 * 3] = float("nan")                 # the same bits at the same place: still not equal
+        t = f.stage_chunks([("particles/position", fl.DeviceField.from_tensor(dpos, columns=(0, 3)))])
+        assert f.compare_staged(t, 0, [ref_nan.view(torch.uint8)]) == [False]
+        with pytest.raises(RuntimeError):
+            f.compare_staged(t, 0, [ref_rows[:1200]])           # too short to repeat
+        f.end_frame()
 
 
 def test_long_trajectory_with_reopen_matches_the_host_path(tmp_path):
@@ -566,8 +647,9 @@ def test_four_ranks_as_threads_append_through_pgsd_hoomd(tmp_path):
 
 
 def test_exact_mode_elides_an_array_that_returns_to_frame_0(tmp_path):
-    """`device_elision = 'exact'`: no array is ever taken off the comparisons, so the density that differs in frame 2
-    only is elided again from frame 3 on -- the host path's file for all five frames."""
+    """`device_elision = 'exact'` (round 3's name for what is now the default): no array is ever taken off the
+    comparisons, so the density that differs in frame 2 only is elided again from frame 3 on -- the host path's file
+    for all five frames."""
     import pgsd.fl as fl
     import pgsd.hoomd as hoomd
     frames = _trajectory(np.random.default_rng(21), 4000, 5)

@@ -175,7 +175,7 @@ class Model:
 
     def should_write(self, path, name, data, default, frame_index, rows=None):
         """hoomd.py:654-694 for ONE rank's value `data` (None = not set).  rows: with several ranks a per-particle
-        array is compared with THAT RANK'S rows of frame 0 (`HOOMDTrajectory._host_elision_votes`) -- while the
+        array is compared with THAT RANK'S rows of frame 0 (`HOOMDTrajectory._host_row_votes`) -- while the
         partition is frame 0's; against the whole of frame 0, as the sketch compares, it could never be equal."""
         if data is None:
             return False
@@ -193,34 +193,16 @@ class Model:
             return False
         return True
 
-    def device_votes(self, chunk, name, local, counts, frame_index):
-        """GPU-resident per-particle attribute: frame 0 is written in full; later an array is skipped when every rank's
-        packed rows equal its rows of frame 0 BYTE FOR BYTE -- as long as the partition is frame 0's and the array has
-        not differed before (`HOOMDTrajectory._device_elision_votes`)."""
-        if all(v is None for v in local):
-            return False
-        if frame_index == 0 or self.dev_off or chunk in self.dev_dynamic or chunk not in self.frame0_chunks:
-            return True
-        row0 = [sum(counts[:r]) for r in range(self.P)]
-        init = self.initial["particles"][name]
-        same = all(v is not None and np.ascontiguousarray(init[row0[r]:row0[r] + counts[r]]).tobytes() == v.tobytes()
-                   for r, v in enumerate(local))
-        if not same:
-            self.dev_dynamic.add(chunk)
-        return not same
-
     def append(self, g, counts, frame_index, device=False):
-        """device=True: the per-particle attributes are GPU-resident (compared on the GPU: `device_votes`)."""
+        """device=True: the per-particle attributes are GPU-resident.  They are decided by the same rule as host
+        arrays (`HOOMDTrajectory._device_votes`: numpy's equality on the GPU, against this rank's rows of frame 0 or
+        against the default value), so the model does not tell the two apart."""
         P = self.P
         if frame_index == 0:
             self.counts0, self.part_off = list(counts), False
         elif list(counts) != self.counts0:
             self.part_off = True            # particles moved between ranks / their number changed: frame 0's rows are
                                             # other particles' from now on (several ranks: no more comparisons)
-        if device and frame_index == 0:
-            self.dev_counts, self.dev_off, self.dev_dynamic = list(counts), False, set()
-        elif device and list(counts) != self.dev_counts:
-            self.dev_off = True             # the same for GPU-resident arrays (one rank too)
         n_global = sum(counts)
         row0 = [sum(counts[:r]) for r in range(P)]
         written = []
@@ -241,10 +223,7 @@ class Model:
                     elif path == "configuration" and name == "box":
                         v = np.ascontiguousarray(v, dtype=np.float32)
                     local.append(v)
-                if device and path == "particles" and name not in REPLICATED:
-                    if not self.device_votes(path + "/" + name, name, local, counts, frame_index):
-                        continue
-                elif not any(self.should_write(path, name, local[r], default, frame_index,
+                if not any(self.should_write(path, name, local[r], default, frame_index,
                                                slice(row0[r], row0[r] + counts[r])
                                                if P > 1 and path == "particles" and name not in REPLICATED else None)
                              for r in range(P)):

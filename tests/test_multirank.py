@@ -79,6 +79,39 @@ def _worker(rank, world, port, path, counts, mode):
                 fr.particles.typeid = S.gen_data(3, seed, row0, n, 1)[:, 0] % 3 + 1
             t.append(fr)
         t.close()
+    elif mode == "hoomd_partition_change":
+        # frame 1 has another partition (known only from the frame's allgather); rank 0's own count is
+        # unchanged, it elides position and velocity against ITS rows of frame 0 -- the other ranks, whose counts
+        # changed, cannot compare (and leave the velocity unset).  Whether those chunks are written must be decided
+        # alike on every rank
+        t = hoomd.open(path, 'w')
+        c1 = [counts[0]] + [c + d for c, d in zip(counts[1:], [1, -1] + [0] * (world - 3))]
+        for frame, cs in enumerate((counts, c1, c1)):
+            n1, r1 = cs[rank], sum(cs[:rank])
+            fr = hoomd.Frame()
+            fr.configuration.step = frame
+            fr.particles.N = n1
+            fr.particles.position = S.gen_data(9, 400, r1, n1, 3)
+            if frame == 0 or rank == 0:
+                fr.particles.velocity = S.gen_data(9, 401, r1, n1, 3)
+            t.append(fr)
+        t.close()
+    elif mode == "hoomd_log_shapes_differ":
+        t = hoomd.open(path, 'w')
+        fr = hoomd.Frame()
+        fr.configuration.step = 0
+        fr.particles.N = n
+        fr.particles.position = S.gen_data(9, 500, row0, n, 3)
+        fr.log['energy'] = np.zeros(3 + (rank == world - 1))            # one rank brings a longer array
+        try:
+            t.append(fr)
+            outcome = "appended"
+        except ValueError as e:
+            outcome = "ValueError" if "the ranks differ" in str(e) else "ValueError?"
+        with open(path + ".rank%d" % rank, "w") as out:
+            out.write(outcome)
+        t.file.end_frame()          # every rank left the frame at the same point: the file goes on
+        t.close()
     elif mode == "hoomd_lone_compare":
         # frame 1 writes nothing but the buffered step chunk (every array elided), so pgsd_end_frame does
         # not flush and metadata stays pending; in frame 2 rank 0 ALONE compares an array it has not compared before
@@ -267,3 +300,39 @@ def test_hoomd_append_one_rank_alone_compares_an_array_while_metadata_is_pending
     for frame in (1, 2, 3):                     # everything but the step was elided
         assert not f.chunk_exists(frame, 'particles/position') and not f.chunk_exists(frame, 'particles/velocity')
     f.close()
+
+
+def test_hoomd_append_partition_change_is_decided_alike_on_every_rank(tmp_path):
+    """after the partition changed, `_elision_outcome` rewrote plan entries to "write" on the ranks
+    that had compared (a rank-local condition) -- one rank placed a chunk the others did not.  Now the ranks carry
+    "elided against my rows of frame 0" in the vote and decide from the gathered bits: the chunks are written by all,
+    the ranks without a velocity contribute default rows."""
+    counts = [4, 2, 5]
+    P = len(counts)
+    mine = str(tmp_path / "traj.gsd")
+    tmp_mp.spawn(_worker, args=(P, free_port(), mine, counts, "hoomd_partition_change"), nprocs=P, join=True)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgsd-sph_amd"))
+    import pgsd.hoomd as hoomd
+    Ng = sum(counts)
+    with hoomd.open(mine, 'r') as t:
+        assert len(t) == 3
+        vel = S.gen_data(9, 401, 0, Ng, 3)
+        for frame in range(3):
+            s = t[frame]
+            assert s.particles.N == Ng
+            np.testing.assert_array_equal(s.particles.position, S.gen_data(9, 400, 0, Ng, 3))
+            want = vel.copy()
+            if frame > 0:
+                want[counts[0]:] = 0                    # only rank 0 set it: the others' rows are the default
+                assert t.file.chunk_exists(frame, 'particles/velocity') and t.file.chunk_exists(frame, 'particles/position')
+            np.testing.assert_array_equal(s.particles.velocity, want)
+
+
+def test_hoomd_append_replicated_shapes_must_agree(tmp_path):
+    """with a declared partition a log / state / replicated chunk is placed from this rank's own
+    size; a rank that brings another shape would silently shift its replicated offsets.  The shapes ride in the vote
+    (a digest): every rank raises the same ValueError, nobody has written anything of the frame."""
+    counts = [3, 4]
+    mine = str(tmp_path / "traj.gsd")
+    tmp_mp.spawn(_worker, args=(2, free_port(), mine, counts, "hoomd_log_shapes_differ"), nprocs=2, join=True)
+    assert [open(mine + ".rank%d" % r).read() for r in range(2)] == ["ValueError", "ValueError"]

@@ -61,7 +61,6 @@ def main():
         """n frames, each sealed asynchronously; returns (seconds until the file has them, max wait for a pack)."""
         f = fl.open(path, "w", application="overlap probe", schema="hoomd", schema_version=[1, 4])
         f.frame_exchange = True
-        f.configure_device(profile=True)                     # event-timed copies: d2h_GBps
         t0 = time.perf_counter()
         worst = 0.0
         for i in range(n_frames):
@@ -108,7 +107,7 @@ def main():
             s, e = run_queue()
             side.synchronize()
             alone.append(s.elapsed_time(e) / launches)
-        under, cover, stalls, d2h = [], [], [], []
+        under, cover, stalls = [], [], []
         for _ in range(3):
             s, e = run_queue()
             dt, worst, stats = drain(args.frames)
@@ -117,7 +116,6 @@ def main():
             under.append(ms / launches)
             cover.append(min(1.0, dt * 1e3 / ms))
             stalls.append(worst * 1e3)
-            d2h.append(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6)
         a_ms, u_ms = min(alone), min(under)
         print(json.dumps({"kernel": kind, "what": what, "label": args.label, "launches": launches,
                           "ms_per_launch_alone": round(a_ms, 4), "ms_per_launch_under_drain": round(u_ms, 4),
@@ -125,8 +123,7 @@ def main():
                           "all_alone_ms": [round(x, 4) for x in alone], "all_under_ms": [round(x, 4) for x in under],
                           "drain_covers_fraction_of_queue": round(min(cover), 3),
                           "frames": args.frames, "particles": N, "frame_MB": N * 28 / 1e6,
-                          "drain_s_alone": round(t_drain, 3), "max_wait_for_pack_ms": round(max(stalls), 3),
-                          "d2h_GBps": round(min(d2h), 2)}))
+                          "drain_s_alone": round(t_drain, 3), "max_wait_for_pack_ms": round(max(stalls), 3)}))
         sys.stdout.flush()
 
 
