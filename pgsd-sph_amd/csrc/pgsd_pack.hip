@@ -16,7 +16,7 @@
 //     LDS, no barrier; every wave instruction covers one contiguous span of whole 128-byte lines (1 KiB
 //     loads, 768-byte / 256-byte stores).  One launch per frame: blockIdx.y = source array, dense
 //     same-type arrays ride along as 16-byte-per-lane copies.  Runs at the rate of a bare register float4
-//     copy of the same bytes (tools/pack_lab.hip, profiles/r02_*).
+//     copy of the same bytes (the round-2 lab, profiles/r02_pack_lab*).
 //   LDS-tiled (pack_tiles_kernel and its variants, round 1): a source tile (contiguous in memory) is
 //     streamed into LDS with 16-byte-per-lane loads, re-packed / converted between LDS and registers and
 //     streamed out with 16-byte-per-lane stores.  Takes what the row kernel does not: 1- and 2-byte
@@ -459,7 +459,7 @@ template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_pr
 // consecutive rows, so every wave instruction still covers one contiguous span of memory --
 // 1 KiB per float4 load, 768 B per N x 3 float store, 256 B per scalar store, all of them whole
 // 128-byte lines -- which is what the memory system needs; the 16-byte-per-lane rule is not.
-// Measured on MI355X (tools/pack_lab.hip, profiles/r02_pack_lab*.jsonl): this shape runs the
+// Measured on MI355X (the round-2 lab, profiles/r02_pack_lab*.jsonl): this shape runs the
 // headline workload at the rate of a bare register float4 copy of the same bytes (93-95 us for
 // 600 MB at 10 M particles), where the LDS-staged tile kernel below needs 104-107 us: the
 // stage -> barrier -> emit phases cost more than the odd store widths.
@@ -908,7 +908,7 @@ template<bool W32> __global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_
 // row i of each chunk (12 bytes + 4 bytes: contiguous pieces, consecutive lanes consecutive rows), and
 // stores ONE 16-byte row (two for a double4 destination restored from f32 chunks).  No LDS, no barrier;
 // blockIdx.y = destination array; dense same-type arrays ride along as 16-byte copies.  Measured in the lab
-// (tools/pack_lab.hip, profiles/r02_lab_unpack.jsonl): 100 us for position + id + velocity + mass of 10 M
+// (the round-2 lab, profiles/r02_lab_unpack.jsonl): 100 us for position + id + velocity + mass of 10 M
 // particles where the LDS-tiled unpack needs 113 us.  A first, fully generic version of this kernel (run-time
 // chunk lists and widths) was no faster than the tiled one; the static hot path is what pays.
 template<bool F64> __device__ __forceinline__ void unrows_store(uint32_t* drow, const uint32_t* w, uint32_t nw, uint32_t col0)

@@ -375,7 +375,7 @@ class _AppendPlan(object):
         self.n_local = 0
         self.part0 = None       # the partition this rank's rows of frame 0 belong to (None: no such comparisons now)
         self.ticket = None      # staging ticket of the device arrays (None: they leave in fused launches)
-        self.compared = []      # positions in `dev` that were compared on the GPU
+        self.compared = []      # positions in `dev` that were compared with this rank's rows of frame 0 on the GPU
         self.frame0_equal = []  # positions in `entries` elided because they equal THIS rank's rows of frame 0
         self.part_dist = None
         self.n_global = 0
@@ -870,7 +870,8 @@ class HOOMDTrajectory(object):
         for k, (at, chunk, _) in enumerate(dev):
             if refs[k] is None:
                 continue
-            plan.compared.append(k)
+            if kinds[k] == 'rows':
+                plan.compared.append(k)
             if equal[k]:
                 plan.entries[at][2] = False
                 if kinds[k] == 'rows':
