@@ -139,6 +139,7 @@ static int rccl_break(RcclCtx* c, const std::string& why)
         hipError_t q;
         while ((q = hipEventQuery(c->done)) == hipErrorNotReady && seconds_since(t0) < 5.0)
             usleep(1000);
+        (void)hipGetLastError();
         if (q != hipSuccess)
             c->stuck = true;
         }
@@ -158,6 +159,7 @@ static int rccl_wait_bounded(RcclCtx* c)
         const hipError_t q = hipEventQuery(c->done);
         if (q == hipSuccess)
             return 0;
+        (void)hipGetLastError(); // "not ready" is the answer, not an error a later hipGetLastError() of this thread should see
         if (q != hipErrorNotReady)
             return rccl_break(c, std::string("RCCL exchange: the stream reports ") + hipGetErrorString(q));
         const double el = seconds_since(t0);

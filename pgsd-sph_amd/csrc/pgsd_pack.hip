@@ -1144,38 +1144,39 @@ __global__ __launch_bounds__(256) void fill_cols_kernel(const FillArgs a)
 // of 10 M rows against 129 us for six equal ones).  A difference further in is still found by the full launch; the
 // first workgroup to see it marks the job and the others stop at their next stride.  The flag words are never
 // cleared: a launch marks with its own generation number.
+// The common case is "equal": the test is shaped for it.  Per 16-byte vector: OR of the XORs (any bit differs?) and, for
+// float chunks, the largest |x| bit pattern of the CHUNK's words shifted left by one (sign out): above 0xff000000 it
+// is a NaN, which equals nothing -- itself included.  Only when bits differ does the slow look decide whether it is
+// a +0.0 / -0.0 pair (equal by value) -- a path an equal array never takes and a different one leaves the kernel on.
 template <int MODE> __device__ __forceinline__ uint32_t cmp_differ16(const u32x4 x, const u32x4 y)
     {
+    const uint32_t differ = (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
     if (MODE == CMP_BYTES)
-        return (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+        return differ;
     if (MODE == CMP_F32)
         {
-        // per word: differ = (bits differ and not both zeros of either sign) or the chunk's word is a NaN
-        // (a NaN in the reference alone differs in its bits anyway)
-        const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
+        const uint32_t m = max(max(x.x << 1, x.y << 1), max(x.z << 1, x.w << 1));
+        uint32_t bad = m > 0xff000000u ? 1u : 0u; // a NaN among the chunk's four floats
+        if (differ != 0)
             {
-            const uint32_t mag = (a[k] | b[k]) & 0x7fffffffu;
-            acc |= ((a[k] ^ b[k]) != 0 && mag != 0) ? 1u : 0u;
-            acc |= ((a[k] & 0x7fffffffu) > 0x7f800000u) ? 1u : 0u;
-            }
-        return acc;
-        }
-    // CMP_F64: two doubles per vector, little endian (low word first)
-    uint32_t acc = 0;
-    const uint32_t al[2] = {x.x, x.z}, ah[2] = {x.y, x.w}, bl[2] = {y.x, y.z}, bh[2] = {y.y, y.w};
+            const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-        {
-        const uint32_t differ = (al[k] ^ bl[k]) | (ah[k] ^ bh[k]);
-        const uint32_t mag = ((ah[k] | bh[k]) & 0x7fffffffu) | al[k] | bl[k];
-        acc |= (differ != 0 && mag != 0) ? 1u : 0u;
-        const uint32_t am = ah[k] & 0x7fffffffu;
-        acc |= (am > 0x7ff00000u || (am == 0x7ff00000u && al[k] != 0)) ? 1u : 0u;
+            for (int k = 0; k < 4; k++) // bits differ: equal all the same when both are zeros of either sign
+                bad |= ((a[k] ^ b[k]) != 0 && ((a[k] | b[k]) << 1) != 0) ? 1u : 0u;
+            }
+        return bad;
         }
-    return acc;
+    // CMP_F64: two doubles per vector, little endian (low word first).  (hi << 1) | (lo != 0) > 0xffe00000: a NaN
+    const uint32_t t0 = (x.y << 1) | (x.x != 0 ? 1u : 0u), t1 = (x.w << 1) | (x.z != 0 ? 1u : 0u);
+    uint32_t bad = max(t0, t1) > 0xffe00000u ? 1u : 0u;
+    if (differ != 0)
+        {
+        const uint32_t al[2] = {x.x, x.z}, ah[2] = {x.y, x.w}, bl[2] = {y.x, y.z}, bh[2] = {y.y, y.w};
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            bad |= (((al[k] ^ bl[k]) | (ah[k] ^ bh[k])) != 0 && (((ah[k] | bh[k]) << 1) | al[k] | bl[k]) != 0) ? 1u : 0u;
+        }
+    return bad;
     }
 
 // one element of `es` bytes (1: a byte of an integer chunk) at byte offset `at`, assembled from bytes: the slow road of

@@ -601,47 +601,29 @@ def test_elision_by_hand_as_integration_md_shows_it(tmp_gsd):
         assert g.read_chunk(2, "particles/position").tobytes() == pos4[:, :3].contiguous().cpu().numpy().tobytes()
 
 
-def test_four_ranks_as_threads_append_through_pgsd_hoomd(tmp_path):
-    """`HOOMDTrajectory.append` on per-handle communicators: four ranks as four THREADS of this process (one
+@pytest.mark.parametrize("kind", ["shm", "rccl"])
+def test_four_ranks_as_threads_append_through_pgsd_hoomd(kind, tmp_path):
+    """`HOOMDTrajectory.append` on per-handle communicators: four ranks as four THREADS of one process (one
     communicator and one file object each, all on cuda:0), arrays in HBM, the elision votes riding in each frame's
-    one allgather -- the file is the model's."""
-    import threading
-    import uuid
-    import pgsd.dist as pdist
-    import pgsd.fl as fl
-    import pgsd.hoomd as hoomd
-    import test_gpu_config4 as C4
+    one allgather -- over the shm back end and over the RCCL back end's code (stand-in librccl: the exchange's
+    polling and the comparison launch share a thread) -- the file is the model's."""
+    import os
+    import subprocess
+    import sys
+    import product
     import test_hoomd_append_oracle as A
     P, seed = 4, 13
     ref, mine = str(tmp_path / "ref.gsd"), str(tmp_path / "mine.gsd")
-    frames = A.random_frames(seed, P)
-    A.expected_file(ref, P, device=True, frames=frames)
-    shm = "pgsdthr_%s" % uuid.uuid4().hex[:10]
-    errors = []
-
-    def rank_main(rank):
-        try:
-            torch.cuda.set_device(0)
-            comm = pdist.create_shm(shm, rank, P)
-            f = fl.open(mine, "w", application="pgsd.hoomd 3.2.0", schema="hoomd", schema_version=[1, 4], comm=comm)
-            t = hoomd.HOOMDTrajectory(f)
-            for k, g in enumerate(frames):
-                fr = C4._device_frame(hoomd, fl, g, g["counts"], rank)
-                if g["explicit"]:
-                    fr.part_dist = np.array(g["counts"], dtype=np.uint64)
-                t.append(fr, wait=(k % 2 == 0))
-            t.close()
-            pdist.release(comm)
-        except Exception:  # pragma: no cover
-            import traceback
-            errors.append((rank, traceback.format_exc()))
-
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join(timeout=300)
-    assert not errors and not any(th.is_alive() for th in threads), errors
+    A.expected_file(ref, P, device=True, frames=A.random_frames(seed, P))
+    env = dict(os.environ)
+    env.pop("PGSD_RCCL_LIBRARY", None)
+    if kind == "rccl":
+        product.build()
+        env.update(PGSD_RCCL_LIBRARY=os.path.join(product.CSRC, "build", "libpgsd_fake_rccl.so"), PGSD_FAKE_RCCL_SYNC="1")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hoomd_threads_worker.py")
+    p = subprocess.run([sys.executable, worker, kind, str(P), str(seed), mine], env=env, capture_output=True, text=True,
+                       timeout=400)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.stdout[-300:], p.stderr[-3000:])
     with open(mine, "rb") as a, open(ref, "rb") as b:
         assert a.read() == b.read()
 
