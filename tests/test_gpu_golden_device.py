@@ -46,3 +46,26 @@ def test_product_golden_device_strided_rows_batched_exchange(name, P, tmp_gsd, t
     """... and with the rows inside wider device arrays (xyz of a Scalar4; a foreign column on either side for the
     other widths: the strided kernels) and the frame's exchange batched -- the way bench.py and pgsd.hoomd write."""
     _replay(name, P, tmp_gsd, tmp_path, 2, 1)
+
+
+FUZZ_SEEDS = int(os.environ.get("PGSD_FUZZ_SEEDS", "16"))
+
+
+@pytest.mark.parametrize("seed,P", [(seed, P) for seed in range(300, 300 + FUZZ_SEEDS) for P in (1, 2, 3)])
+def test_random_scenarios_from_hbm_equal_the_oracle(seed, P, tmp_path):
+    """The random call sequences of tests/test_fuzz_parity.py (random names, types, widths, partitions with empty
+    ranks, default-argument writes, wrong global sizes, buffer limits, mid-frame flushes, re-opens, read-backs) with
+    the rows of every chunk write in HBM: file and state trace identical to the oracle's.  Odd seeds: rows inside
+    wider device arrays and the frame's exchange batched."""
+    from test_fuzz_parity import make_script
+    scn = tmp_path / "fuzz.scn"
+    scn.write_text(make_script(seed, P))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "device.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
+    dscn = product.device_script(str(scn), str(tmp_path / "device.scn"), 2 if seed % 2 else 1, 1 if seed % 2 else 0)
+    p_log = product.run_driver(dscn, p_path, P, driver=product.DEVICE_DRIVER)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
+    strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines]
+    assert strip(p_log) == strip(o_log)
