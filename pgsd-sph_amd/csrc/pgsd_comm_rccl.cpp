@@ -239,6 +239,12 @@ static int rccl_allgather(void* p, const void* send, void* recv, size_t bytes)
         return rccl_break(c, "RCCL exchange: device->host copy failed");
     if (rccl_wait_bounded(c) != 0)
         return -1;
+    // the stream ran dry -- which it also does when RCCL gave an exchange up on its own: the bytes are trusted only when
+    // the communicator reports no asynchronous error
+    ncclResult_t state = ncclSuccess;
+    if (g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(c->comm, &state) == ncclSuccess && state != ncclSuccess
+        && state != ncclInProgress)
+        return rccl_break(c, std::string("RCCL exchange failed asynchronously: ") + nccl_text(state));
     memcpy(recv, c->h_recv, bytes * (size_t)c->size);
     return 0;
     }

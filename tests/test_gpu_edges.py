@@ -388,3 +388,52 @@ def test_direct_chunks_in_one_pwritev_or_one_by_one_are_the_same_file(tmp_path, 
             f.end_frame()
     with open(a, 'rb') as fa, open(b, 'rb') as fb:
         assert fa.read() == fb.read()
+
+
+def test_a_pending_device_read_keeps_its_staging_while_chunks_are_staged(tmp_path):
+    """between `read_chunk_device(wait=False)` and `wait_read` a small read's bytes sit in the pinned
+    arena of the direct path (no outstanding piece is counted for them); a stage() issued in between used to recycle
+    that arena and pack over them before the unpack kernel had read them."""
+    import pgsd.fl as fl
+    rng = np.random.default_rng(5)
+    N = 3000
+    pos = rng.standard_normal((N, 3)).astype(np.float32)
+    other = rng.standard_normal((N, 4)).astype(np.float32)
+    path = str(tmp_path / "t.gsd")
+    with fl.open(path, "w", application="a", schema="hoomd", schema_version=[1, 4]) as f:
+        f.write_chunk("particles/position", pos, offset=np.array([N]))
+        f.end_frame()
+        f.frame_exchange = True
+        dother = torch.from_numpy(other).cuda()
+        for _ in range(4):
+            got = f.read_chunk_device(0, "particles/position", wait=False)          # 36 KB: the direct road
+            t = f.stage_chunks([("particles/velocity", fl.DeviceField.from_tensor(dother, columns=(0, 3)))])
+            f.wait_packed()
+            f.wait_read()
+            assert got.cpu().numpy().tobytes() == pos.tobytes()
+            f.write_staged(t, 0, 1, offset=np.array([N]))
+            f.end_frame()
+    with fl.open(path, "r") as f:
+        assert f.nframes == 5 and f.read_chunk(3, "particles/velocity").tobytes() == np.ascontiguousarray(other[:, :3]).tobytes()
+
+
+def test_parked_pipeline_resources_can_be_released(tmp_path):
+    """A closed handle of the default geometry parks its streams, pinned slabs and staging for the next handle (at most
+    two sets); `pgsd_device_release_parked` gives them back and the next handle builds its own again."""
+    import pgsd.fl as fl
+    from pgsd import _lib
+    pos = torch.rand((5000, 4), device="cuda")
+
+    def one_file(k):
+        with fl.open(str(tmp_path / ("p%d.gsd" % k)), "w", application="a", schema="hoomd", schema_version=[1, 4]) as f:
+            f.write_chunks([("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3)))], offset=np.array([5000]))
+            f.end_frame()
+    _lib.lib.pgsd_device_release_parked()
+    one_file(0)
+    assert _lib.lib.pgsd_device_release_parked() == 1
+    assert _lib.lib.pgsd_device_release_parked() == 0
+    one_file(1)
+    one_file(2)                                      # adopts the set file 1 parked and parks it again
+    assert _lib.lib.pgsd_device_release_parked() == 1
+    with fl.open(str(tmp_path / "p2.gsd"), "r") as f:
+        assert f.read_chunk(0, "particles/position").tobytes() == pos[:, :3].contiguous().cpu().numpy().tobytes()

@@ -200,6 +200,23 @@ def test_a_rank_that_never_arrives_is_a_comm_error_inside_the_deadline(tmp_path)
     assert ends == ["abort", "abort", "destroy"]
 
 
+def test_an_exchange_rccl_gives_up_by_itself_is_not_trusted(tmp_path):
+    """The other way an exchange ends without its peers: the collective library gives up on its own (here the
+    stand-in's waiting kernel leaves at PGSD_FAKE_RCCL_MAX_WAIT_S, long before PGSD_COMM_TIMEOUT_S) and the stream runs
+    dry with nothing gathered.  `ncclCommGetAsyncError` says so, and the call fails instead of returning stale bytes."""
+    product.build()
+    env = dict(os.environ, PGSD_RCCL_LIBRARY=FAKE, PGSD_COMM_TIMEOUT_S="60", PGSD_FAKE_RCCL_MAX_WAIT_S="2",
+               PGSD_FAKE_RCCL_LOG=str(tmp_path / "fake"))
+    p = subprocess.run([sys.executable, "-c", ABSENT % {"pkg": os.path.join(ROOT, "pgsd-sph_amd")}], env=env,
+                       capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-3000:])
+    lines = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("RANK")]
+    assert [ln[1] for ln in lines] == ["0", "1"]
+    for _, _, rc2, s2, msg2, rc3, s3, msg3 in lines:
+        assert int(rc2) != 0 and 1.5 <= float(s2) < 15.0 and "asynchronously" in msg2, (rc2, s2, msg2)
+        assert int(rc3) != 0 and float(s3) < 0.5 and "broken" in msg3, (rc3, s3, msg3)
+
+
 STALLED = r'''
 import os, sys, time
 sys.path.insert(0, %(pkg)r); sys.path.insert(0, %(tests)r)
