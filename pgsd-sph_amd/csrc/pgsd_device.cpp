@@ -286,7 +286,7 @@ class DevicePipeline
         if (m_cfg.n_slabs == 0)
             m_cfg.n_slabs = 16;
         // Buffered writes into ONE file serialise on its inode lock: a second writer thread
-        // halves the rate on tmpfs (profiles/r01_io_probes.md), so one writer is the default.
+        // halves the rate on tmpfs (profiles/r01_io_probe*.log), so one writer is the default.
         if (m_cfg.n_writers == 0)
             m_cfg.n_writers = 1;
         m_direct_max = (size_t)2048 << 10;
