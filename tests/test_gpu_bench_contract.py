@@ -39,6 +39,11 @@ def test_bench_line_has_the_contracts_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "GB/s" and c["value"] > 0
     assert isinstance(c["sample"], str) and "particles" in c["sample"]
+    # what a draining snapshot costs a kernel that runs beside it (the copies are shader blits): measured, not assumed
+    o = d["snapshot_overlap"]
+    assert isinstance(d["snapshot_overlap_slowdown_pct"], float) and d["snapshot_overlap_slowdown_pct"] == o["slowdown_pct"]
+    assert o["launches"] >= 20 and o["ms_per_launch_alone"] > 0 and o["frames_drained"] == 4
+    assert d["snapshot_stall_ms"] > 0
 
 
 def test_bench_measures_its_hbm_traffic_with_the_pmc_counters():
