@@ -324,6 +324,7 @@ def launch_ranks(n, argv):
         signal.signal(sig, stop_children)
     status = 0
     pending = list(procs)
+    failed_at = None
     try:
         while pending:
             for p in list(pending):
@@ -333,9 +334,13 @@ def launch_ranks(n, argv):
                 pending.remove(p)
                 if rc != 0 and status == 0:
                     status = rc if rc > 0 else 1
-                    # a rank that died leaves the others inside a collective: end them (exactly these children)
-                    for q in pending:
-                        q.terminate()
+                    failed_at = time.monotonic()
+            # a rank that died leaves the others inside a collective: they get a few seconds to say why they stop
+            # (the same refusal, a communicator time-out), then they are ended (exactly these children)
+            if failed_at is not None and pending and time.monotonic() - failed_at > 5.0:
+                for q in pending:
+                    q.terminate()
+                failed_at = float("inf")
             if pending:
                 time.sleep(0.05)
     finally:

@@ -41,3 +41,25 @@ def test_self_launch_starts_n_ranks_and_reports_their_failure():
     assert p.returncode != 0
     assert p.stdout.strip() == ""                               # no JSON line claims a run that did not happen
     assert p.stderr.count("needs an MI355X") == 2               # both ranks were started and said why
+
+
+def test_target_file_system_is_named():
+    """`config.target_fstype` comes from /proc/mounts (longest mount point that holds the directory): a 1 -> 8 curve
+    whose points landed on different file systems shows it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.fstype_of("/proc/self") == "proc"
+    if os.path.isdir("/dev/shm"):
+        assert bench.fstype_of("/dev/shm") == "tmpfs"
+    assert bench.fstype_of(ROOT) not in (None, "proc", "sysfs")
+    assert bench.fstype_of("/no/such/dir/anywhere") is not None           # falls to the root's
+
+
+def test_ranks_get_the_ipc_mode_the_pool_needs():
+    """bench.py exports HSA_ENABLE_IPC_MODE_LEGACY=0 to itself (setdefault) before torch / HIP load, for self-launched
+    and launcher-started ranks alike: the hosts only support dmabuf IPC handles, without which RCCL's intra-node
+    transport fails in hipIpcGetMemHandle."""
+    src = open(BENCH).read()
+    at_set = src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")')
+    assert at_set < src.index("import torch\n", src.index("def main()"))
+    assert 'HSA_ENABLE_IPC_MODE_LEGACY="0"' not in src                     # no longer only in the self-launch path
