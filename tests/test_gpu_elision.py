@@ -664,3 +664,49 @@ def test_device_reader_without_default_rows(tmp_path):
         assert a.particles.body is not None and int(a.particles.body[0]) == -1 and b.particles.body is None
         assert b.particles.image is None and b.particles.mass.cpu().numpy().tobytes() == frames[0][3].tobytes()
         assert b.particles.position.cpu().numpy().tobytes() == frames[1][1].tobytes()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_compare_staged_random_cases_against_numpy(seed, tmp_gsd):
+    """`compare_staged` against `numpy.array_equal` on random chunks: float32 / float64 / int32, 1-4 columns, sizes on
+    both sides of the direct-path threshold, NaNs and zeros of either sign sprinkled in, one element changed somewhere
+    (or nothing), zero signs flipped -- with a full-size reference and with a short one that repeats."""
+    import pgsd.fl as fl
+    rng = np.random.default_rng(7000 + seed)
+    dt = [np.float32, np.float64, np.int32][seed % 3]
+    M = int(rng.integers(1, 5))
+    N = int(rng.choice([1, 5, 333, 4096, 4097, 70_001, 300_000]))
+    periodic = bool(rng.random() < 0.5) and N * M * np.dtype(dt).itemsize > 16384
+    if periodic:
+        rows = 4096 if (4096 * M * np.dtype(dt).itemsize) % 16 == 0 else 4096 * 4
+        pattern = (rng.standard_normal((rows, M)) * 3).astype(dt)
+        if dt != np.int32 and rng.random() < 0.5:
+            pattern.reshape(-1)[rng.integers(0, pattern.size, size=20)] = 0.0
+        a = np.tile(pattern, (N // rows + 1, 1))[:N].copy()
+        ref = pattern
+    else:
+        a = (rng.standard_normal((N, M)) * 3).astype(dt)
+        if dt != np.int32 and rng.random() < 0.5:
+            a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 40))] = 0.0
+        ref = a.copy()
+    what = rng.choice(["same", "flip_zeros", "change_one", "nan_both", "nan_chunk"])
+    if what == "flip_zeros" and dt != np.int32:
+        z = a == 0
+        a[z] = -a[z]                                        # equal by value, different bytes
+    elif what == "change_one":
+        i = (int(rng.integers(0, N)), int(rng.integers(0, M)))
+        a[i] = a[i] + 1 if dt == np.int32 else a[i] * 2 + 1
+    elif what == "nan_both" and dt != np.int32 and not periodic:
+        i = (int(rng.integers(0, N)), int(rng.integers(0, M)))
+        a[i] = ref[i] = np.nan                              # the same bits on both sides: still not equal
+    elif what == "nan_chunk" and dt != np.int32:
+        a[int(rng.integers(0, N)), int(rng.integers(0, M))] = np.nan
+    full = np.tile(ref, (N // ref.shape[0] + 1, 1))[:N] if periodic else ref
+    want = bool(np.array_equal(a, full))
+    da = torch.from_numpy(a).cuda()
+    dref = torch.from_numpy(np.ascontiguousarray(ref).view(np.uint8).reshape(-1)).cuda()
+    with fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4]) as f:
+        f.frame_exchange = True
+        t = f.stage_chunks([("log/x", da)])
+        assert f.compare_staged(t, 0, [dref]) == [want], (seed, dt, N, M, periodic, what)
+        f.end_frame()
