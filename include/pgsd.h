@@ -234,7 +234,10 @@ extern "C"
        and every chunk is placed at once from that knowledge, byte for byte where the exchanges would have put it
        (every golden and fuzz scenario is replayed this way).  Errors: a call that fails this rank's checks returns
        the code at once; the other ranks learn of it at the next synchronisation point (pgsd_flush / pgsd_close / a
-       read), like a failed write; the frame's barrier is made up there too, as with the batched exchange.
+       read), like a failed write; the frame's barrier is made up there too, as with the batched exchange.  That
+       exchange also compares the ranks' views of the file (size, frame counter, numbers of names and index entries):
+       ranks that brought different sizes for a chunk that is not partitioned -- the one thing the declaration takes
+       on trust -- all get PGSD_ERROR_COMM there instead of going on with different layouts of one file.
        rows == NULL clears the declaration.  Every rank must declare the same vector (n_ranks = the communicator's
        size). */
     int pgsd_set_partition(struct pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks);

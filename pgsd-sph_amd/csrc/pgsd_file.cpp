@@ -308,22 +308,39 @@ static void publish(pgsd_handle* h, Impl* s)
     h->nprocs = s->P;
     }
 
-// every rank learns the first non-zero status (rank order) and its errno
-static int agree_status(Impl* s, int local_rc)
+// every rank learns the first non-zero status (rank order) and its errno.  check_state (the flush's exchange): the
+// ranks also compare what they believe about the file -- its size, the frame counter, the number of names and of index
+// entries.  The metadata is replicated, not broadcast (the reference lets rank 0's view win, pgsd.c:2219-2222): it
+// stays identical as long as every rank makes the same calls with sizes that agree -- which the exchanges check, and a
+// DECLARED partition (pgsd_set_partition) takes on trust for chunks that are not partitioned.  A caller
+// that broke that trust is told here, on every rank, instead of leaving ranks with different layouts of one file.
+static int agree_status(Impl* s, int local_rc, bool check_state = false)
     {
     if (s->P == 1)
         return local_rc;
-    int32_t mine[2] = {local_rc, local_rc ? errno : 0};
-    std::vector<int32_t> all((size_t)s->P * 2);
+    uint64_t mine[5] = {(uint64_t)(uint32_t)local_rc | ((uint64_t)(uint32_t)(local_rc ? errno : 0) << 32), (uint64_t)s->file_size,
+                        s->cur_frame, s->file_n_names, s->file_index_size};
+    std::vector<uint64_t> all((size_t)s->P * 5);
     if (s->gather(mine, all.data(), sizeof(mine)) != 0)
         return PGSD_ERROR_COMM;
     for (int r = 0; r < s->P; r++)
-        if (all[(size_t)r * 2] != 0)
+        if ((int32_t)(uint32_t)all[(size_t)r * 5] != 0)
             {
             if (local_rc == 0)
-                errno = all[(size_t)r * 2 + 1];
-            return all[(size_t)r * 2];
+                errno = (int)(uint32_t)(all[(size_t)r * 5] >> 32);
+            return (int32_t)(uint32_t)all[(size_t)r * 5];
             }
+    for (int r = 1; r < s->P && check_state; r++)
+        for (int k = 1; k < 5; k++)
+            if (all[(size_t)r * 5 + k] != all[(size_t)k])
+                {
+                static const char* what[5] = {"", "file size", "frame counter", "number of names", "number of index entries"};
+                set_last_error(std::string("the ranks disagree about the file (") + what[k] + ": "
+                               + std::to_string(all[(size_t)k]) + " on rank 0, " + std::to_string(all[(size_t)r * 5 + k])
+                               + " on rank " + std::to_string(r)
+                               + "): a chunk that is not partitioned was written with different sizes on different ranks");
+                return PGSD_ERROR_COMM;
+                }
     return PGSD_SUCCESS;
     }
 
@@ -808,7 +825,7 @@ static int do_flush(Impl* s, bool async = false, bool sync_point = true)
         return local_rc != PGSD_SUCCESS ? local_rc : qrc;
         }
     s->unsynced = false;
-    const int arc = agree_status(s, local_rc);
+    const int arc = agree_status(s, local_rc, true);
     return arc != PGSD_SUCCESS ? arc : qrc;
     }
 

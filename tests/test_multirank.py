@@ -79,6 +79,25 @@ def _worker(rank, world, port, path, counts, mode):
                 fr.particles.typeid = S.gen_data(3, seed, row0, n, 1)[:, 0] % 3 + 1
             t.append(fr)
         t.close()
+    elif mode == "fl_declared_mismatch":
+        # a declared partition takes the sizes of chunks that are not partitioned on trust; here the ranks bring
+        # different lengths: the next synchronisation point tells every rank
+        f = fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4])
+        f.set_partition(counts)
+        f.write_chunk('particles/position', S.gen_data(9, 1, row0, n, 3), offset="auto")
+        f.write_chunk('log/values', np.zeros(4 + rank))
+        f.end_frame()
+        try:
+            f.flush()
+            outcome = "flushed"
+        except RuntimeError as e:
+            outcome = "RuntimeError" if "disagree about the file (file size" in str(e) else "RuntimeError? " + str(e)
+        with open(path + ".rank%d" % rank, "w") as out:
+            out.write(outcome)
+        try:
+            f.close()
+        except RuntimeError:
+            pass
     elif mode == "hoomd_partition_change":
         # frame 1 has another partition (known only from the frame's allgather); rank 0's own count is
         # unchanged, it elides position and velocity against ITS rows of frame 0 -- the other ranks, whose counts
@@ -336,3 +355,13 @@ def test_hoomd_append_replicated_shapes_must_agree(tmp_path):
     mine = str(tmp_path / "traj.gsd")
     tmp_mp.spawn(_worker, args=(2, free_port(), mine, counts, "hoomd_log_shapes_differ"), nprocs=2, join=True)
     assert [open(mine + ".rank%d" % r).read() for r in range(2)] == ["ValueError", "ValueError"]
+
+
+def test_declared_partition_ranks_that_disagree_about_the_file_are_told(tmp_path):
+    """ADVICE r3 (low), C-ABI side: with pgsd_set_partition a chunk that is not partitioned is placed from this rank's
+    own size; ranks that bring different sizes end up with different layouts of one file.  The flush's status exchange
+    now carries every rank's view of the file (size, frame counter, names, index entries) and all ranks fail alike."""
+    counts = [3, 4]
+    mine = str(tmp_path / "traj.gsd")
+    tmp_mp.spawn(_worker, args=(2, free_port(), mine, counts, "fl_declared_mismatch"), nprocs=2, join=True)
+    assert [open(mine + ".rank%d" % r).read() for r in range(2)] == ["RuntimeError", "RuntimeError"]
