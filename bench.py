@@ -520,7 +520,7 @@ def main():
     # landed on different file systems (tmpfs 7 GB/s, page cache 11 GB/s) would not be a curve -- unless
     # --dir-fallback allows the first of /tmp and the working directory that has the room.  Either way the JSON names
     # the directory and its file system type (config.target_dir / config.target_fstype).
-    extra = 4 if world == 1 and not args.no_stall_test else 1
+    extra = 4 + 5 * 4 if world == 1 and not args.no_stall_test else 1    # 3 stall-test frames, 5 drains of 4 frames beside a kernel queue
     need = world * (args.warmup + args.steps + extra) * N * payload_bpp + (256 << 20)
     choice = [None]
     if rank == 0:

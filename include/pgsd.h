@@ -9,8 +9,9 @@
  * What changed underneath:
  *   - no <mpi.h>: ranks talk through a small communicator vtable (part 2); back ends are
  *     "self", a single-node shared-memory segment, RCCL over xGMI, or host callbacks
- *     (torch.distributed).  The reference's ~10 collectives per chunk become zero for
- *     per-particle chunks and one 8-byte allgather for replicated small chunks.
+ *     (torch.distributed).  The reference's ~10 collectives per chunk become one small
+ *     allgather per chunk -- or ONE per frame (pgsd_set_frame_exchange), or none at all
+ *     (pgsd_set_partition).
  *   - all metadata (names, index, file size) is replicated deterministically on every
  *     rank; only rank 0 writes it.  pgsd_find_chunk() is therefore valid on every rank.
  *   - part 3 adds the device path: chunks are packed from HBM-resident particle arrays
