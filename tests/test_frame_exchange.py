@@ -26,8 +26,9 @@ class MirrorComm:
             self.calls.append(nbytes)
             ctypes.memmove(recv, send, nbytes)
             ctypes.memmove(recv + nbytes, send, nbytes)
-            if peer_empty and nbytes > 16:
-                # a frame exchange [status, count, sizes...]: the peer made the same calls with no rows
+            if peer_empty and nbytes >= 512:
+                # a frame exchange [status, count, sizes...] (512 bytes; the flush's status exchange, 40 bytes, carries
+                # the ranks' views of the file, which are the same): the peer made the same calls with no rows
                 ctypes.memset(recv + nbytes + 16, 0, nbytes - 16)
             return 0
 
