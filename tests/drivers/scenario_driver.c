@@ -64,6 +64,9 @@
  *                                   shows the same file_size the unbatched run shows)
  *   device <0|1|2>                 (PGSD_DRIVER_DEVICE build only, see above; refused by the other product builds,
  *                                   ignored by the reference build)
+ *   async <0|1>                    (product builds: `end_frame` seals with pgsd_end_frame_async -- metadata committed at
+ *                                   once, device copies and pwrites running on behind the caller -- instead of
+ *                                   pgsd_end_frame; the layout must not change by a byte; ignored by the reference build)
  *   end_frame | flush | close | dump
  *   maxbuf <bytes> | idxbuf <entries>
  *   find <frame> <name>            (prints found/N/M/type/location on rank 0)
@@ -274,6 +277,7 @@ static enum pgsd_open_flag parse_flag(const char* s)
 
 /* rows of chunk writes that must outlive the call (batch 2: pgsd_set_deferred_rows): freed at the next
    end_frame / flush / close / dump, all of which resolve the queue */
+static __thread int g_async = 0;   /* `async 1`: frames are sealed with pgsd_end_frame_async */
 static __thread int g_trusted = 0; /* batch 3 */
 static __thread void** g_kept = NULL;
 static __thread int g_nkept = 0;
@@ -618,6 +622,17 @@ static int run_script(const char* script, const char* path)
             }
         else if (strcmp(cmd, "end_frame") == 0)
             {
+#ifndef PGSD_DRIVER_REF
+            if (g_async)
+                {
+                rc = pgsd_end_frame_async(&handle);
+#ifdef PGSD_DRIVER_DEVICE
+                if (rc == 0)
+                    rc = pgsd_device_wait_packed(&handle); /* the rows are freed below: the pack must have read them */
+#endif
+                }
+            else
+#endif
             rc = pgsd_end_frame(&handle);
             free_kept_rows();
 #ifdef PGSD_DRIVER_DEVICE
@@ -675,6 +690,8 @@ static int run_script(const char* script, const char* path)
             return 2;
 #endif
             }
+        else if (strcmp(cmd, "async") == 0 && nt == 2)
+            g_async = atoi(tok[1]);
         else if (strcmp(cmd, "localreads") == 0 && nt == 2)
             {
 #ifndef PGSD_DRIVER_REF

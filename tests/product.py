@@ -102,10 +102,10 @@ def local_reads_script(path, out_path):
     return out_path
 
 
-def device_script(path, out_path, mode=1, batch=0):
+def device_script(path, out_path, mode=1, batch=0, async_seal=False):
     """The same scenario with the rows of every chunk write in HBM (`device <mode>` behind create / open; the
     scenario_driver_device build): 1 = dense device arrays, 2 = rows inside wider arrays.  `batch` as in
-    :func:`batched_script`."""
+    :func:`batched_script`; `async_seal`: frames sealed with pgsd_end_frame_async."""
     lines = []
     with open(path) as f:
         for line in f:
@@ -115,6 +115,8 @@ def device_script(path, out_path, mode=1, batch=0):
             lines.append(line)
             if tok and tok[0] in ("create", "open"):
                 lines.append("device %d\n" % mode)
+                if async_seal:
+                    lines.append("async 1\n")
                 if batch and tok[0] == "create" or (tok[0] == "open" and tok[1] != "ro" and batch):
                     lines.append("batch %d\n" % batch)
     with open(out_path, "w") as f:

@@ -20,8 +20,8 @@ from test_product_golden import _fails_on_purpose
 pytestmark = pytest.mark.gpu
 
 
-def _replay(name, P, tmp_gsd, tmp_path, mode, batch):
-    scn = product.device_script(S.scenario_path(name), str(tmp_path / "device.scn"), mode, batch)
+def _replay(name, P, tmp_gsd, tmp_path, mode, batch, async_seal=False):
+    scn = product.device_script(S.scenario_path(name), str(tmp_path / "device.scn"), mode, batch, async_seal)
     golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
     log = product.run_driver(scn, tmp_gsd, P, allow_fail=_fails_on_purpose(golden), driver=product.DEVICE_DRIVER,
                              threads=P > 5)
@@ -31,7 +31,7 @@ def _replay(name, P, tmp_gsd, tmp_path, mode, batch):
     assert mine == ref
     # the inserted `device` / `batch` lines shift the line numbers the driver prints
     strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines
-                           if not ln.startswith("rc ") or ("cmd=batch" not in ln and "cmd=device" not in ln)]
+                           if not ln.startswith("rc ") or not any(c in ln for c in ("cmd=batch", "cmd=device", "cmd=async"))]
     assert strip(log) == strip(S.read_log(golden[:-4] + ".log"))
 
 
@@ -46,6 +46,14 @@ def test_product_golden_device_strided_rows_batched_exchange(name, P, tmp_gsd, t
     """... and with the rows inside wider device arrays (xyz of a Scalar4; a foreign column on either side for the
     other widths: the strided kernels) and the frame's exchange batched -- the way bench.py and pgsd.hoomd write."""
     _replay(name, P, tmp_gsd, tmp_path, 2, 1)
+
+
+@pytest.mark.parametrize("name,P", [c for c in S.golden_cases() if c[1] in (1, 2, 4, 8)])
+def test_product_golden_device_asynchronous_seals(name, P, tmp_gsd, tmp_path):
+    """... and with every frame sealed asynchronously (pgsd_end_frame_async: the metadata of the frame committed at
+    once, copies and pwrites running on behind the caller; index relocations fall back to the synchronous seal): the
+    layout does not change by a byte, reads and re-opens in the scenarios see complete frames."""
+    _replay(name, P, tmp_gsd, tmp_path, 1, 1, async_seal=True)
 
 
 FUZZ_SEEDS = int(os.environ.get("PGSD_FUZZ_SEEDS", "16"))
