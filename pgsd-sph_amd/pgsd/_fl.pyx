@@ -187,6 +187,57 @@ cdef class DeviceField:
         return cls(ptr, s, N, M, stride=stride, col0=col0,
                    out_dtype=out_dtype, order=order_ptr, bitcast=bitcast, keepalive=keep)
 
+    @classmethod
+    def from_device_array(cls, a, out_dtype=None, bitcast=False, columns=None, order=None):
+        """Build from any object that describes GPU memory through ``__cuda_array_interface__`` (version 2 or 3; the
+        protocol ROCm builds of HOOMD's GPU snapshots, CuPy, Numba and PyTorch share): shape ``(N,)``, ``(N, M)`` or a
+        column range ``columns=(c0, c1)`` of ``(N, S)`` -- a ``Scalar4`` array --, row-major, rows possibly strided.
+        ``order``: an optional 32-bit integer array of the same kind (gather index).  The arrays must be complete when
+        the chunk is written (the protocol's ``stream`` entry is not waited on: order the producer against
+        :meth:`PGSDFile.set_source_stream`, or synchronise it)."""
+        if _is_device_tensor(a):
+            return cls.from_tensor(a, out_dtype=out_dtype, order=order, bitcast=bitcast, columns=columns)
+        iface = getattr(a, '__cuda_array_interface__', None)
+        if not isinstance(iface, dict) or 'data' not in iface or 'shape' not in iface or 'typestr' not in iface:
+            raise ValueError("not a GPU array: no __cuda_array_interface__")
+        dt = numpy.dtype(iface['typestr'])
+        if dt.byteorder == '>':
+            raise ValueError("big-endian device arrays are not supported")
+        shape = tuple(int(x) for x in iface['shape'])
+        if len(shape) == 1:
+            shape = (shape[0], 1)
+        elif len(shape) != 2:
+            raise ValueError("PGSD can only write 1 or 2 dimensional arrays")
+        N, S = shape
+        strides = iface.get('strides')
+        if strides is None:
+            row = S
+        else:
+            strides = tuple(int(x) for x in strides) if len(iface['shape']) == 2 else (int(strides[0]), dt.itemsize)
+            if (S > 1 and strides[1] != dt.itemsize) or strides[0] % dt.itemsize != 0:
+                raise ValueError("device arrays must be row-major with element-aligned rows")
+            row = strides[0] // dt.itemsize if N > 1 else S
+        c0, c1 = (0, S) if columns is None else (int(columns[0]), int(columns[1]))
+        if not (0 <= c0 < c1 <= S) or row < S:
+            raise ValueError("columns outside the array's rows")
+        ptr = int(iface['data'][0]) if N * S > 0 else 0
+        keep = [a]
+        order_ptr = None
+        if order is not None:
+            if _is_device_tensor(order):
+                o_ptr, o_dt, o_n = order.data_ptr(), numpy.dtype(str(order.dtype)[6:]), int(order.shape[0])
+                dense = order.dim() == 1 and order.is_contiguous()
+            else:
+                oi = order.__cuda_array_interface__
+                o_ptr, o_dt, o_n = int(oi['data'][0]), numpy.dtype(oi['typestr']), int(oi['shape'][0])
+                dense = len(oi['shape']) == 1 and oi.get('strides') in (None, (4,))
+            if o_dt not in (numpy.dtype('<i4'), numpy.dtype('<u4')) or not dense:
+                raise ValueError("order must be a contiguous 32-bit integer device array")
+            order_ptr, N = o_ptr, o_n
+            keep.append(order)
+        return cls(ptr, dt, N, c1 - c0, stride=max(row, 1), col0=c0, out_dtype=out_dtype, order=order_ptr,
+                   bitcast=bitcast, keepalive=keep)
+
     cdef void fill_desc(self, C.pgsd_field_desc* d):
         d.src = <const void*><uintptr_t>self.ptr
         d.order = <const uint32_t*><uintptr_t>(self.order if self.order is not None else 0)
@@ -214,6 +265,18 @@ cdef class DeviceField:
 
 def _is_device_tensor(x):
     return hasattr(x, 'data_ptr') and getattr(x, 'is_cuda', False)
+
+
+def _is_device_array(x):
+    """A torch GPU tensor, or any other object that describes GPU memory through ``__cuda_array_interface__``."""
+    if _is_device_tensor(x):
+        return True
+    if hasattr(x, 'data_ptr'):
+        return False                    # a torch tensor in host memory (its __cuda_array_interface__ raises)
+    try:
+        return isinstance(getattr(x, '__cuda_array_interface__', None), dict)
+    except Exception:
+        return False
 
 
 def select_rows(flags):
@@ -568,7 +631,7 @@ cdef class PGSDFile:
                 ``False``: replicated small chunk.
         """
         self._check_open()
-        if isinstance(data, DeviceField) or _is_device_tensor(data):
+        if isinstance(data, DeviceField) or _is_device_array(data):
             return self._write_chunk_device(name, data, offset, rank, write_all)
 
         data_array = numpy.ascontiguousarray(data)
@@ -657,7 +720,7 @@ cdef class PGSDFile:
     def _write_chunk_device(self, name, data, offset, rank, write_all):
         if not self._explicit_stream:
             self._sync_source_stream()
-        cdef DeviceField f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
+        cdef DeviceField f = data if isinstance(data, DeviceField) else DeviceField.from_device_array(data)
         cdef uint64_t N = f.N, N_global, stride
         cdef uint32_t M = f.M
         py_ng, py_stride = self._partition_args(offset, rank, N, M)
@@ -703,7 +766,7 @@ cdef class PGSDFile:
         try:
             for i in range(n):
                 name, data = fields[i]
-                f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
+                f = data if isinstance(data, DeviceField) else DeviceField.from_device_array(data)
                 if i == 0:
                     N = f.N
                 elif <uint64_t>f.N != N:
@@ -745,7 +808,7 @@ cdef class PGSDFile:
         try:
             for i in range(n):
                 name, data = fields[i]
-                f = data if isinstance(data, DeviceField) else DeviceField.from_tensor(data)
+                f = data if isinstance(data, DeviceField) else DeviceField.from_device_array(data)
                 if i == 0:
                     N = f.N
                 elif <uint64_t>f.N != N:

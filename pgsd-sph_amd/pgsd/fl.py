@@ -16,6 +16,6 @@ except ImportError as e:  # pragma: no cover - a checkout that was never built
                       "(or python -c 'import __graft_entry__ as g; g.build()'): %s" % e)
 
 from ._fl import DeviceField, PGSDFile, open, select_rows, logger  # noqa: E402,F401
-from ._fl import _is_device_tensor, _pgsd_type, _NP_TO_PGSD, _PGSD_TO_NP  # noqa: E402,F401
+from ._fl import _is_device_tensor, _is_device_array, _pgsd_type, _NP_TO_PGSD, _PGSD_TO_NP  # noqa: E402,F401
 
 __all__ = ["open", "PGSDFile", "DeviceField", "select_rows"]

@@ -38,7 +38,7 @@ _HOST_TYPES = (numpy.ndarray, numpy.generic, int, float, list, tuple, str)
 def _is_device(x):
     if isinstance(x, _HOST_TYPES):      # the common case first: no attribute lookups on the torch side
         return False
-    return fl is not None and (isinstance(x, fl.DeviceField) or fl._is_device_tensor(x))
+    return fl is not None and (isinstance(x, fl.DeviceField) or fl._is_device_array(x))
 
 
 _READER_FIELDS = {}
@@ -74,7 +74,10 @@ def _schema_names(frame):
 def _rows(x):
     if fl is not None and isinstance(x, fl.DeviceField):
         return x.N
-    return int(x.shape[0])
+    shape = getattr(x, 'shape', None)
+    if shape is None:                   # a bare __cuda_array_interface__ object
+        shape = x.__cuda_array_interface__['shape']
+    return int(shape[0])
 
 
 class ConfigurationData(object):
@@ -560,7 +563,7 @@ class HOOMDTrajectory(object):
                 per_particle = particles and (name in _PARTICLE_SPEC or name in _PARTICLE_SPEC_EXTRA)
                 if per_particle and _is_device(value):
                     dt, _ = (_PARTICLE_SPEC.get(name) or _PARTICLE_SPEC_EXTRA.get(name))
-                    field = value if isinstance(value, fl.DeviceField) else fl.DeviceField.from_tensor(value, out_dtype=dt)
+                    field = value if isinstance(value, fl.DeviceField) else fl.DeviceField.from_device_array(value, out_dtype=dt)
                     dev.append((len(entries), path + '/' + name, field))
                     entries.append([path, name, True])
                     continue

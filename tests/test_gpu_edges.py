@@ -437,3 +437,63 @@ def test_parked_pipeline_resources_can_be_released(tmp_path):
     assert _lib.lib.pgsd_device_release_parked() == 1
     with fl.open(str(tmp_path / "p2.gsd"), "r") as f:
         assert f.read_chunk(0, "particles/position").tobytes() == pos[:, :3].contiguous().cpu().numpy().tobytes()
+
+
+class _BareDeviceArray(object):
+    """What a GPU simulation that is not PyTorch hands over: an object that describes its device memory through
+    ``__cuda_array_interface__`` and nothing else (HOOMD's GPU snapshot arrays, CuPy, Numba)."""
+
+    def __init__(self, t, readonly=False):
+        self._keep = t
+        self.__cuda_array_interface__ = {
+            "shape": tuple(t.shape), "typestr": np.dtype(str(t.dtype)[6:]).str, "data": (t.data_ptr(), readonly),
+            "version": 3, "strides": None if t.is_contiguous() else tuple(s * t.element_size() for s in t.stride())}
+
+
+def test_arrays_that_only_speak_the_cuda_array_interface(tmp_path):
+    """`write_chunk`, `write_chunks`, `DeviceField.from_device_array` and `HOOMDTrajectory.append` take device arrays
+    from any producer that implements ``__cuda_array_interface__``: dense arrays, the xyz columns of a Scalar4 array,
+    strided rows, a gather index.  Same files as from torch tensors / host arrays."""
+    import pgsd.fl as fl
+    import pgsd.hoomd as hoomd
+    rng = np.random.default_rng(11)
+    N = 4321
+    pos4 = rng.standard_normal((N, 4)).astype(np.float32)
+    tid = rng.integers(0, 5, size=N).astype(np.int32)
+    dens = rng.standard_normal(N).astype(np.float64)
+    order = rng.permutation(N).astype(np.int32)
+    dpos4, dtid, ddens, dorder = dev(pos4), dev(tid), dev(dens), dev(order)
+    a, b = str(tmp_path / "bare.gsd"), str(tmp_path / "torch.gsd")
+    for path, wrap in ((a, _BareDeviceArray), (b, lambda t: t)):
+        with fl.open(path, "w", application="a", schema="hoomd", schema_version=[1, 4]) as f:
+            f.write_chunk("particles/typeid", wrap(dtid), offset=np.array([N]))
+            f.write_chunks([("particles/position", fl.DeviceField.from_device_array(wrap(dpos4), columns=(0, 3))),
+                            ("particles/charge", fl.DeviceField.from_device_array(wrap(dpos4), columns=(3, 4))),
+                            ("particles/density", fl.DeviceField.from_device_array(wrap(ddens), out_dtype=np.float32))],
+                           offset=np.array([N]))
+            f.write_chunk("particles/velocity", fl.DeviceField.from_device_array(wrap(dpos4[:, 1:4]), order=wrap(dorder)),
+                          offset=np.array([N]))
+            f.end_frame()
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+    with fl.open(a, "r") as f:
+        assert f.read_chunk(0, "particles/position").tobytes() == np.ascontiguousarray(pos4[:, :3]).tobytes()
+        assert f.read_chunk(0, "particles/velocity").tobytes() == np.ascontiguousarray(pos4[order][:, 1:4]).tobytes()
+        assert f.read_chunk(0, "particles/density").tobytes() == dens.astype(np.float32).tobytes()
+    # through pgsd.hoomd, elision included: a bare device array, a host array -- the same trajectory file
+    c, d = str(tmp_path / "h_bare.gsd"), str(tmp_path / "h_host.gsd")
+    pos = np.ascontiguousarray(pos4[:, :3])
+    dpos = dev(pos)
+    for path, put in ((c, lambda h, t: _BareDeviceArray(t)), (d, lambda h, t: h)):
+        with hoomd.open(path, "w") as t:
+            for k in range(3):
+                fr = hoomd.Frame()
+                fr.configuration.step = k
+                fr.particles.N = N
+                fr.particles.position = put(pos, dpos)
+                fr.particles.typeid = put(tid.view(np.uint32), dtid)
+                t.append(fr)
+    with open(c, "rb") as fc, open(d, "rb") as fd:
+        assert fc.read() == fd.read()
+    with pytest.raises(ValueError):
+        fl.DeviceField.from_device_array(object())
