@@ -857,7 +857,10 @@ class HOOMDTrajectory(object):
         if not any(kinds):
             return
         ticket = f.stage_chunks([(chunk, field) for _, chunk, field in dev])
-        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else 0
+        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else None
+        if device is None:              # fields built from bare pointers: the pipeline runs on the current device
+            import torch
+            device = torch.cuda.current_device()
         row0 = sum(part0[:rank]) if part0 is not None else 0
         for k, (_, chunk, field) in enumerate(dev):
             if kinds[k] == 'default':
