@@ -156,8 +156,19 @@ def pmc_pass(counter, child_args, timeout):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def under_a_profiler():
+    """Is this process itself running under rocprofv3 (its tool library preloaded)?  Then no counter passes are started
+    from inside it: a profiler's child would inherit the outer tool next to its own."""
+    return ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ
+            or any(k.startswith("ROCPROF_") for k in os.environ))
+
+
 def measure_traffic_live(args):
     """-> (HBM bytes per frame's pack launch(es), source text, detail) from two PMC passes, or Nones."""
+    if under_a_profiler():
+        print("bench.py: running under a profiler: no nested counter passes (roofline.traffic from profiles/pack_traffic.json)",
+              file=sys.stderr)
+        return None, None, None
     child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--particles", str(args.particles), "--schema", args.schema,
              "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test", "--no-exchange-probe"]
     if args.separate_id:
