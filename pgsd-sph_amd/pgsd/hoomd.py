@@ -397,7 +397,8 @@ class HOOMDTrajectory(object):
             with this rank's rows of frame 0 where frame 0 holds the chunk, with the default value where it does
             not -- and the file is the one host arrays of the same values give, for every input (NaNs, signed zeros,
             arrays that return to frame 0's values, default-valued arrays); the price is one frame's worth of HBM for
-            the rows of frame 0 and one comparison launch per frame.  ``'once'``: an array that differed once is
+            the rows of frame 0 and one comparison launch per frame.  ``'once'`` (``'bytes-once'`` is accepted for it:
+            round 3's default, whose comparison was of bytes; equality is numpy's in every mode now): an array that differed once is
             written from then on without a comparison (a moving array costs nothing after the first frame; an array
             that returns to frame 0's values is written where the host path would elide it).  False: GPU-resident
             arrays are always written.
@@ -659,7 +660,7 @@ class HOOMDTrajectory(object):
             self._dev_ref.clear()
             self._host_ref.clear()
             return
-        if self.device_elision == 'once':
+        if self.device_elision in ('once', 'bytes-once'):
             for k in plan.compared:
                 at, chunk, _ = plan.dev[k]
                 if plan.entries[at][2]:
