@@ -222,7 +222,6 @@ extern "C"
        covering a sealed frame is made up at the next pgsd_flush / pgsd_close / read or by the next
        frame's exchange.  Collective like pgsd_end_frame when it turns batching off. */
     int pgsd_set_frame_exchange(struct pgsd_handle* handle, int batched);
-    int pgsd_get_frame_exchange(struct pgsd_handle* handle);
     /* Declared partition: NO exchange per chunk and none per frame.  The caller tells the library every rank's
        row count -- what a size exchange would tell it -- because it has exchanged the counts itself (pgsd.hoomd's
        one allgather per frame carries them next to its write/skip votes) or because they have not changed since
@@ -548,12 +547,10 @@ extern "C"
         uint32_t M;
         struct pgsd_field_desc src;
         };
-    int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream);
-    /* The same, timed: *kernel_ms receives the time from the begin of the first to the end of the last
-       kernel of the call as the dispatches themselves stamp it (what rocprofv3 reports per kernel; no
-       launch latency).  Synchronises `stream`.  Measurement only (tools/pack_bench.py). */
-    int pgsd_pack_fields_timed(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream,
-                               float* kernel_ms);
+    /* kernel_ms (may be NULL): receives the time from the begin of the first to the end of the last kernel of the call
+       as the dispatches themselves stamp it (what rocprofv3 reports per kernel; no launch latency); the call then
+       synchronises `stream`.  Measurement only (tools/pack_bench.py). */
+    int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream, float* kernel_ms);
 
     /* Stream compaction for filtered snapshots: out_index[k] = i for the k-th row whose
        flag byte is non-zero (stable), *out_count (device uint64) = number selected.

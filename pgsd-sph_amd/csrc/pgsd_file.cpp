@@ -2153,18 +2153,6 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_get_frame_exchange(struct pgsd_handle* handle)
-    try
-    {
-    Impl* s = impl_of(handle);
-    return s && s->batch ? 1 : 0;
-    }
-catch (...)
-    {
-        pgsd_amd::abi_guard();
-        return 0;
-    }
-
 // ---------------------------------------------------------------------------- device path
 
 extern "C" int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg)

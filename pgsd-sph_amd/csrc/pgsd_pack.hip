@@ -2326,43 +2326,30 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream)
+extern "C" int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream, float* kernel_ms)
     try
     {
     if (n_jobs > 0 && !jobs)
         return PGSD_ERROR_INVALID_ARGUMENT;
+    if (kernel_ms)
+        *kernel_ms = 0.f;
     if (!pgsd_device_available())
         {
         set_last_error("pgsd_pack_fields: no HIP device visible (the HIP path has no CPU fallback)");
         return PGSD_ERROR_NO_DEVICE;
         }
     std::string err;
-    int rc = launch_pack(n_jobs, jobs, N, (hipStream_t)stream, &err);
-    if (rc != PGSD_SUCCESS)
-        set_last_error(err);
-    return rc;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
-
-extern "C" int pgsd_pack_fields_timed(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream,
-                                      float* kernel_ms)
-    try
-    {
-    if ((n_jobs > 0 && !jobs) || !kernel_ms)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    *kernel_ms = 0.f;
-    if (!pgsd_device_available())
+    if (!kernel_ms)
         {
-        set_last_error("pgsd_pack_fields_timed: no HIP device visible (the HIP path has no CPU fallback)");
-        return PGSD_ERROR_NO_DEVICE;
+        int rc = launch_pack(n_jobs, jobs, N, (hipStream_t)stream, &err);
+        if (rc != PGSD_SUCCESS)
+            set_last_error(err);
+        return rc;
         }
+    // timed: the dispatches' own begin / end stamps (what rocprofv3 reports per kernel; no launch latency)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return PGSD_ERROR_DEVICE;
-    std::string err;
     int rc = launch_pack(n_jobs, jobs, N, (hipStream_t)stream, &err, e0, e1);
     if (rc != PGSD_SUCCESS)
         set_last_error(err);

@@ -334,7 +334,7 @@ cdef class PGSDFile:
     cdef bint _is_open
     cdef object _mode, _name, _comm
     cdef list _keepalive, _async_keep
-    cdef bint _explicit_stream, _deferred_rows, _local_reads
+    cdef bint _explicit_stream, _deferred_rows, _local_reads, _frame_exchange_on
     cdef object _source_stream
 
     def __init__(self, name, mode, application, schema, schema_version, comm=None):
@@ -375,6 +375,7 @@ cdef class PGSDFile:
         self._name = name
         self._keepalive = []
         self._explicit_stream = False
+        self._frame_exchange_on = False
         self._source_stream = -1       # what the pipeline was last told (-1: nothing yet)
         self._deferred_rows = False
         self._local_reads = False
@@ -521,7 +522,7 @@ cdef class PGSDFile:
         chunks (``offset='auto'``) and ``end_frame`` costs one collective.  The file is byte-identical
         either way."""
         self._check_open()
-        return bool(C.pgsd_get_frame_exchange(&self._handle))
+        return bool(self._frame_exchange_on)
 
     @frame_exchange.setter
     def frame_exchange(self, on):
@@ -531,6 +532,7 @@ cdef class PGSDFile:
             retval = C.pgsd_set_frame_exchange(&self._handle, flag)
             err = errno
         _raise_on_error(retval, self._name, err)
+        self._frame_exchange_on = flag != 0
 
     @property
     def deferred_rows(self):

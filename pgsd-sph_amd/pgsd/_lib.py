@@ -196,10 +196,8 @@ _sig("pgsd_device_wait_packed", c_i32, HP)
 _sig("pgsd_device_set_source_stream", c_i32, HP, c_vp)
 _sig("pgsd_device_configure", c_i32, HP, ctypes.POINTER(DeviceConfig))
 _sig("pgsd_device_get_stats", c_i32, HP, ctypes.POINTER(DeviceStats), c_i32)
-_sig("pgsd_pack_fields", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp)
-_sig("pgsd_pack_fields_timed", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp, ctypes.POINTER(ctypes.c_float))
+_sig("pgsd_pack_fields", c_i32, c_u32, ctypes.POINTER(PackJob), c_u64, c_vp, ctypes.POINTER(ctypes.c_float))
 _sig("pgsd_set_frame_exchange", c_i32, HP, c_i32)
-_sig("pgsd_get_frame_exchange", c_i32, HP)
 _sig("pgsd_frame_exchange", c_i32, HP)
 _sig("pgsd_set_deferred_rows", c_i32, HP, c_i32)
 _sig("pgsd_set_local_reads", c_i32, HP, c_i32)

@@ -108,7 +108,6 @@ cdef extern from "pgsd.h" nogil:
 
     # ---- frame exchange, communicators
     int pgsd_set_frame_exchange(pgsd_handle* handle, int batched)
-    int pgsd_get_frame_exchange(pgsd_handle* handle)
     int pgsd_set_deferred_rows(pgsd_handle* handle, int on)
     int pgsd_set_local_reads(pgsd_handle* handle, int on)
     int pgsd_set_partition(pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks)

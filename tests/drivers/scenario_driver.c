@@ -278,6 +278,7 @@ static enum pgsd_open_flag parse_flag(const char* s)
 /* rows of chunk writes that must outlive the call (batch 2: pgsd_set_deferred_rows): freed at the next
    end_frame / flush / close / dump, all of which resolve the queue */
 static __thread int g_async = 0;   /* `async 1`: frames are sealed with pgsd_end_frame_async */
+static __thread int g_batched = 0; /* pgsd_set_frame_exchange is on (batch 1, 2) */
 static __thread int g_trusted = 0; /* batch 3 */
 static __thread void** g_kept = NULL;
 static __thread int g_nkept = 0;
@@ -509,6 +510,7 @@ static int run_script(const char* script, const char* path)
             }
         else if (strcmp(cmd, "create") == 0 && nt == 7)
             {
+            g_batched = 0; /* a new handle starts with the per-chunk exchange */
 #if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
             if (g_own_comm)
                 rc = pgsd_create_and_open_on(&g_comm, &handle, path, tok[1], tok[2],
@@ -522,6 +524,7 @@ static int run_script(const char* script, const char* path)
             }
         else if (strcmp(cmd, "open") == 0 && nt == 2)
             {
+            g_batched = 0;
 #if !defined(PGSD_DRIVER_REF) && !defined(PGSD_DRIVER_MPI)
             if (g_own_comm)
                 rc = pgsd_open_on(&g_comm, &handle, path, parse_flag(tok[1]));
@@ -666,7 +669,10 @@ static int run_script(const char* script, const char* path)
             if (g_trusted)
                 rc = 0;
             else
+                {
                 rc = pgsd_set_frame_exchange(&handle, atoi(tok[1]) != 0);
+                g_batched = rc == 0 && atoi(tok[1]) != 0;
+                }
             if (rc == 0 && atoi(tok[1]) == 2)
                 {
                 rc = pgsd_set_deferred_rows(&handle, 1);
@@ -701,7 +707,7 @@ static int run_script(const char* script, const char* path)
         else if (strcmp(cmd, "dump") == 0)
             {
 #ifndef PGSD_DRIVER_REF
-            if (pgsd_get_frame_exchange(&handle))
+            if (g_batched)
                 {
                 rc = pgsd_frame_exchange(&handle);
                 free_kept_rows();

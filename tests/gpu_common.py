@@ -48,7 +48,7 @@ def hip_pack(jobs, N, stream=None):
         arr[i].src.src_col0 = col0
         arr[i].src.bitcast = 1 if bitcast else 0
     torch.cuda.synchronize()
-    rc = _lib.lib.pgsd_pack_fields(len(jobs), arr, N, ctypes.c_void_p(stream) if stream else None)
+    rc = _lib.lib.pgsd_pack_fields(len(jobs), arr, N, ctypes.c_void_p(stream) if stream else None, None)
     assert rc == 0, (rc, _lib.last_error())
     torch.cuda.synchronize()
 

@@ -44,7 +44,7 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     if _lib.lib.pgsd_device_available():
         return
     job = (_lib.PackJob * 1)()
-    assert _lib.lib.pgsd_pack_fields(1, job, 16, None) == _lib.ERROR_NO_DEVICE
+    assert _lib.lib.pgsd_pack_fields(1, job, 16, None, None) == _lib.ERROR_NO_DEVICE
     assert "no HIP device" in _lib.last_error()
     ws = ctypes.c_uint64(0)
     assert _lib.lib.pgsd_select_rows(None, 0, None, ctypes.byref(ws), ctypes.byref(ws), None) == _lib.ERROR_NO_DEVICE

@@ -91,7 +91,7 @@ def test_random_fused_pack(seed):
         outs.append(out)
         expect.append(G.oracle_pack(a, M, col0=col0, out_dtype=ddt, order=order, bitcast=bitcast))
     torch.cuda.synchronize()
-    rc = _lib.lib.pgsd_pack_fields(nf, jobs, N, None)
+    rc = _lib.lib.pgsd_pack_fields(nf, jobs, N, None, None)
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
     for i, (out, exp) in enumerate(zip(outs, expect)):

@@ -113,7 +113,7 @@ def test_all_types_same_type(dt, stride, M, col0):
     job[0].src.src_stride = stride
     job[0].src.src_col0 = col0
     torch.cuda.synchronize()
-    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None, None) == 0
     torch.cuda.synchronize()
     check(out, G.oracle_pack(src, M, col0=col0))
 
@@ -141,7 +141,7 @@ def test_conversions(sdt, ddt):
     job[0].src.src_stride = stride
     job[0].src.src_col0 = col0
     torch.cuda.synchronize()
-    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None, None) == 0
     torch.cuda.synchronize()
     check(out, G.oracle_pack(src, M, col0=col0, out_dtype=ddt))
 
@@ -157,7 +157,7 @@ def test_unsupported_conversion_is_rejected():
     job[0].src.src = d.data_ptr()
     job[0].src.src_type = G.type_id("float32")
     job[0].src.src_stride = 1
-    assert _lib.lib.pgsd_pack_fields(1, job, 16, None) == _lib.ERROR_INVALID_ARGUMENT
+    assert _lib.lib.pgsd_pack_fields(1, job, 16, None, None) == _lib.ERROR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("N", [1, 1000, 1025, 70001])
@@ -183,7 +183,7 @@ def test_gather_in_tag_order(N, sdt, stride, M, ddt):
     job[0].src.src_type = G.type_id(sdt)
     job[0].src.src_stride = stride
     torch.cuda.synchronize()
-    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None, None) == 0
     torch.cuda.synchronize()
     check(out, G.oracle_pack(src, M, out_dtype=ddt, order=order))
 
@@ -204,7 +204,7 @@ def test_unaligned_pointers_take_the_generic_kernel():
     job[0].src.src_type = G.type_id("float32")
     job[0].src.src_stride = 4
     torch.cuda.synchronize()
-    assert _lib.lib.pgsd_pack_fields(1, job, N, None) == 0
+    assert _lib.lib.pgsd_pack_fields(1, job, N, None, None) == 0
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     assert got[4:4 + N * 12].tobytes() == G.oracle_pack(src, 3).tobytes()

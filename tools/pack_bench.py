@@ -126,7 +126,7 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
     stream = torch.cuda.current_stream().cuda_stream
     for i in range(warmup):
         arr, n, _ = sets[i % n_sets]
-        assert _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream)) == 0, _lib.last_error()
+        assert _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream), None) == 0, _lib.last_error()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     import time
@@ -148,10 +148,10 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
         if KERNEL_ONLY:
             # the dispatches' own begin / end stamps (what rocprofv3 reports): no launch latency in the figure
             ms = ctypes.c_float(0)
-            assert _lib.lib.pgsd_pack_fields_timed(n, arr, N, ctypes.c_void_p(stream), ctypes.byref(ms)) == 0
+            assert _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream), ctypes.byref(ms)) == 0
             kernel_ms.append(ms.value)
         else:
-            _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream))
+            _lib.lib.pgsd_pack_fields(n, arr, N, ctypes.c_void_p(stream), None)
         evs[i][1].record()
     torch.cuda.synchronize()
     ts = np.array(kernel_ms if KERNEL_ONLY else [a.elapsed_time(b) for a, b in evs]) * 1e-3
@@ -177,7 +177,7 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="", help="comma list of variants to interleave launch by launch: "
                     "KEY=VALUE[+KEY=VALUE] settings of the PGSD_PACK_* variables")
     ap.add_argument("--kernel-only", action="store_true",
-                    help="time with the dispatches' own stamps (pgsd_pack_fields_timed) instead of stream events "
+                    help="time with the dispatches' own stamps (pgsd_pack_fields' kernel_ms) instead of stream events "
                          "around the call")
     a = ap.parse_args()
     KERNEL_ONLY = a.kernel_only
