@@ -35,12 +35,12 @@ ALGO_BYTES_PER_PARTICLE = 56   # read pos.xyz + vel.xyz + typeid (28 B) + write 
 PAYLOAD_BYTES_PER_PARTICLE = 28
 
 
-def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1):
+def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
     """Time the reference ITSELF (oracle/_ref/ref_bench = the reference's pgsd.c compiled in the
     build container + tests/drivers/ref_bench.c) under MPICH on this host's cores: `ranks` MPI ranks
-    (one core each, one per GPU of the run, as SURVEY 8(d) prescribes) writing `n_particles` each,
-    plus a second run on more ranks (min(4 * ranks, nproc)) of the same total workload to show what
-    more cores buy.  None when it cannot run."""
+    (one core each, one per GPU of the run, as SURVEY 8(d) prescribes; `mpiexec -bind-to core`: every rank
+    pinned to a core of its own) writing `n_particles` each, plus a second run on more ranks
+    (min(4 * ranks, nproc)) of the same total workload to show what more cores buy.  None when it cannot run."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     mpiexec = "/opt/conda/bin/mpiexec"
@@ -52,8 +52,8 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1):
     res = {}
     try:
         for r in sorted({ranks, more}):
-            out = subprocess.run([mpiexec, "-n", str(r), exe, str(n_particles * ranks), str(frames), path],
-                                 capture_output=True, timeout=300, check=True).stdout.decode()
+            out = subprocess.run([mpiexec, "-bind-to", "core", "-n", str(r), exe, str(n_particles * ranks), str(frames),
+                                  path, schema], capture_output=True, timeout=300, check=True).stdout.decode()
             res[r] = json.loads(out.strip().splitlines()[-1])
     except Exception as e:  # missing MPI runtime, time-out, ...
         print("bench.py: reference baseline unavailable (%s), using the oracle port" % e, file=sys.stderr)
@@ -64,10 +64,14 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1):
     return {"value": round(res[ranks]["GBps"], 4), "unit": "GB/s", "cores": ranks, "kind": "reference",
             "nproc": nproc, "ranks": ranks,
             "more_cores": {"ranks": more, "value": round(res[more]["GBps"], 4)},
-            "sample": "%d frames x %d particles per rank (pos+vel+typeid): C pack loop out of float4 arrays + the "
+            "binding": "mpiexec -bind-to core (one core per rank; not NUMA-matched to the GPUs)", "schema": schema,
+            "sample": "%d frames x %d particles per rank (%s): C pack loop out of float4 arrays + the "
                       "reference's pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), %d rank(s) = %d core(s) of %d, "
+                      "each rank bound to a core of its own (mpiexec -bind-to core), "
                       "one shared file on %s; the same total workload on %d ranks: %.3f GB/s"
-                      % (frames, n_particles, ranks, ranks, nproc, out_dir, more, res[more]["GBps"])}
+                      % (frames, n_particles, {"pvi": "pos+vel+typeid", "sph": "the 14 chunks of the SPH schema, 112 B/particle",
+                                               "union": "the 19 chunks of SPH + upstream HOOMD, 164 B/particle"}[schema],
+                         ranks, ranks, nproc, out_dir, more, res[more]["GBps"])}
 
 
 def cpu_baseline(n_particles, frames, out_dir):
@@ -170,7 +174,7 @@ def measure_traffic_live(args):
               file=sys.stderr)
         return None, None, None
     child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--particles", str(args.particles), "--schema", args.schema,
-             "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test", "--no-exchange-probe"]
+             "--dir", args.dir, "--no-cpu-baseline", "--traffic", "off", "--no-stall-test", "--no-exchange-probe", "--no-legs"]
     if args.separate_id:
         child.append("--separate-id")
     fetch = pmc_pass("FETCH_SIZE", child, 240)
@@ -394,6 +398,9 @@ def main():
                     help="pgsd_set_partition instead of the per-frame allgather: every rank's row count is declared once "
                          "(weak scaling: the same on all ranks), frames then cost NO collective (collectives_per_frame 0). "
                          "The default keeps the north_star's shape: one allgather of chunk sizes per frame")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="N=1, --schema pvi: skip the `legs` (BASELINE configs 2, 4, 5 and the tag-order gather measured "
+                         "after the headline; bench_legs.py)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and a gloo group")
     args = ap.parse_args()
@@ -469,61 +476,13 @@ def main():
                 comm_backend = pdist.init_from_torch(device=local_rank, prefer_rccl=False)
 
     N = args.particles
-    # HOOMD's own device layout (ParticleData: Scalar4 pos = x, y, z, __int_as_scalar(type);
-    # Scalar4 vel = vx, vy, vz, mass).  --separate-id keeps the id in its own uint32 array as
-    # SURVEY.md 8(d) sketches; both layouts have 56 algorithmic bytes per particle.
+    # HBM-resident particle arrays of this rank and the chunks they feed (bench_legs.make_fields: HOOMD's own
+    # device layout, Scalar4 pos = x, y, z, __int_as_scalar(type); Scalar4 vel = vx, vy, vz, mass; the full schemas
+    # add HOOMD-SPH's Scalar4 / int4 / scalar arrays)
+    import bench_legs
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    pos = (torch.rand((N, 4), generator=g, device="cuda") - 0.5) * 100.0
-    vel = torch.randn((N, 4), generator=g, device="cuda")
-    tid = torch.randperm(N, generator=g, device="cuda").to(torch.int32)
-    if args.separate_id:
-        id_field = fl.DeviceField.from_tensor(tid, out_dtype=np.uint32)
-        layout = "float4 pos, float4 vel, separate uint32 id array"
-    else:
-        pos[:, 3] = tid.view(torch.float32)
-        id_field = fl.DeviceField.from_tensor(pos, columns=(3, 4), out_dtype=np.uint32, bitcast=True)
-        layout = "HOOMD Scalar4 arrays: pos=(x,y,z,typeid bits), vel=(vx,vy,vz,mass)"
-    fields = [("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
-              ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
-              ("particles/typeid", id_field)]
-
-    payload_bpp, algo_bpp = PAYLOAD_BYTES_PER_PARTICLE, ALGO_BYTES_PER_PARTICLE
-    if args.schema in ("sph", "union"):
-        # hoomd.py:167-184: typeid, mass, body, position, velocity, slength, density, pressure, energy,
-        # auxiliary1-4, image -- from HOOMD-SPH-style device arrays (Scalar4 / int3-as-int4 / int)
-        dpe = torch.rand((N, 4), generator=g, device="cuda")                 # density, pressure, energy, slength
-        aux = [torch.randn((N, 4), generator=g, device="cuda") for _ in range(4)]
-        img = torch.randint(-2, 3, (N, 4), generator=g, device="cuda", dtype=torch.int32)
-        body = torch.full((N,), -1, device="cuda", dtype=torch.int32)
-        fields = [("particles/typeid", id_field),
-                  ("particles/mass", fl.DeviceField.from_tensor(vel, columns=(3, 4))),
-                  ("particles/body", fl.DeviceField.from_tensor(body)),
-                  ("particles/position", fl.DeviceField.from_tensor(pos, columns=(0, 3))),
-                  ("particles/velocity", fl.DeviceField.from_tensor(vel, columns=(0, 3))),
-                  ("particles/slength", fl.DeviceField.from_tensor(dpe, columns=(3, 4))),
-                  ("particles/density", fl.DeviceField.from_tensor(dpe, columns=(0, 1))),
-                  ("particles/pressure", fl.DeviceField.from_tensor(dpe, columns=(1, 2))),
-                  ("particles/energy", fl.DeviceField.from_tensor(dpe, columns=(2, 3)))]
-        fields += [("particles/auxiliary%d" % (k + 1), fl.DeviceField.from_tensor(a, columns=(0, 3)))
-                   for k, a in enumerate(aux)]
-        fields.append(("particles/image", fl.DeviceField.from_tensor(img, columns=(0, 3))))
-        payload_bpp, algo_bpp = 112, 224
-        layout = "HOOMD-SPH device arrays (Scalar4 pos/vel/dpe/aux1-4, int4 image, int body), full SPH schema"
-    if args.schema == "union":
-        # BASELINE config 4: the SPH set plus the upstream HOOMD particle attributes (pgsd.tex:508-521):
-        # charge, diameter (Scalar arrays), moment_inertia (Scalar3), orientation, angmom (Scalar4)
-        charge = torch.randn((N,), generator=g, device="cuda")
-        diameter = torch.rand((N,), generator=g, device="cuda")
-        inertia = torch.rand((N, 3), generator=g, device="cuda")
-        orient = torch.randn((N, 4), generator=g, device="cuda")
-        angmom = torch.randn((N, 4), generator=g, device="cuda")
-        fields += [("particles/charge", fl.DeviceField.from_tensor(charge)),
-                   ("particles/diameter", fl.DeviceField.from_tensor(diameter)),
-                   ("particles/moment_inertia", fl.DeviceField.from_tensor(inertia)),
-                   ("particles/orientation", fl.DeviceField.from_tensor(orient)),
-                   ("particles/angmom", fl.DeviceField.from_tensor(angmom))]
-        payload_bpp, algo_bpp = 164, 328
-        layout = "HOOMD-SPH device arrays + upstream HOOMD attributes (charge, diameter, moment_inertia, orientation, angmom)"
+    fields, payload_bpp, algo_bpp, layout, _arrays = bench_legs.make_fields(args.schema, N, g, torch, np, fl,
+                                                                            separate_id=args.separate_id)
 
     # The run appends world x (warmup + steps [+ 3 stall-test frames]) frames to ONE file: 2.24 GB per frame at eight
     # ranks.  A target without that much room would end the run in ENOSPC half-way (a tmpfs is also memory of the
@@ -713,11 +672,27 @@ def main():
         "pipeline": {"d2h_GBps": round(stats["d2h_bytes"] / max(stats["d2h_ms"], 1e-9) / 1e6, 2),
                      "write_GBps_per_writer": round(stats["written_bytes"] / max(stats["write_ms"], 1e-9) / 1e6, 2)},
     }
-    if not args.no_cpu_baseline and args.schema == "pvi":
+    if not args.no_cpu_baseline:
         # the reference's CPU path on this host's cores: one MPI rank per GPU of the run (the other ranks of this
-        # run have left by now); a bounded sample (18 GB of file at most, 10-30 s)
-        out["cpu_baseline"] = (cpu_baseline_reference(N, max(4, 64 // world), args.dir, ranks=world)
-                               or cpu_baseline(N, 8, args.dir))
+        # run have left by now), each bound to a core; a bounded sample (18 GB of file at most, 10-30 s)
+        frames = max(4, 64 // world) if args.schema == "pvi" else max(3, 16 // world)
+        out["cpu_baseline"] = cpu_baseline_reference(N, frames, args.dir, ranks=world, schema=args.schema)
+        if out["cpu_baseline"] is None and args.schema == "pvi":
+            out["cpu_baseline"] = cpu_baseline(N, 8, args.dir)
+    if world == 1 and args.schema == "pvi" and not args.no_legs:
+        # the other BASELINE configurations, into the same line (bench_legs.py): config 2 by SURVEY 8(d)'s protocol,
+        # config 4 (sph, union), config 5's read, the tag-order gather -- kernel time, algorithmic bytes, fraction of
+        # the HBM peak and PMC traffic each
+        import shutil
+        room = shutil.disk_usage(args.dir).free
+        if room < 8 * N * 164 + (256 << 20):
+            out["legs"], out["legs_note"] = [], "skipped: %s has %.1f GB free, the legs write up to %.1f GB" % (
+                args.dir, room / 1e9, 8 * N * 164 / 1e9)
+        else:
+            t_legs = time.perf_counter()
+            out["legs"], out["legs_traffic_source"] = bench_legs.run_legs(N, args.dir, target_fstype,
+                                                                          traffic=(args.traffic == "live" and not under_a_profiler()))
+            out["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
+def run_bench(*extra, legs=False):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--particles", "300000"] + list(extra), capture_output=True, text=True, timeout=600)
+                        "--particles", "300000"] + ([] if legs else ["--no-legs"]) + list(extra),
+                       capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout          # exactly one line on stdout
@@ -39,6 +40,9 @@ def test_bench_line_has_the_contracts_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "GB/s" and c["value"] > 0
     assert isinstance(c["sample"], str) and "particles" in c["sample"]
+    if c["kind"] == "reference":                    # ranks pinned, and the line says how
+        assert "bind-to core" in c["sample"] and "bind-to core" in c["binding"]
+    assert "legs" not in d                          # --no-legs
     # what a draining snapshot costs a kernel that runs beside it (the copies are shader blits): measured, not assumed
     o = d["snapshot_overlap"]
     assert isinstance(d["snapshot_overlap_slowdown_pct"], float) and d["snapshot_overlap_slowdown_pct"] == o["slowdown_pct"]
@@ -120,3 +124,46 @@ def test_a_target_without_room_stops_the_run_instead_of_moving_it():
     assert "has not that much room" in p.stderr and "--dir-fallback" in p.stderr and "nor /tmp" not in p.stderr
     p = subprocess.run(base + ["--dir-fallback"], capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and p.stdout.strip() == "" and "nor /tmp" in p.stderr
+
+
+LEG_NAMES = ["config2", "config4_sph", "config4_union", "config5_read", "gather_uniform", "gather_hilbert"]
+
+
+def test_bench_line_carries_a_leg_for_every_other_baseline_config():
+    """configs 2, 4 (sph, union), 5 and the tag-order gather sit in the driver-run line, each with
+    avg_us / algorithmic_bytes / frac (the reference's harnesses print every leg they run, benchmark-write.cc:144-172,
+    benchmark-read.cc:128-146).  Small particle count here; config 2 keeps its own 2^20 rows."""
+    d = run_bench("--traffic", "off", "--no-cpu-baseline", "--no-stall-test", "--no-exchange-probe", legs=True)
+    legs = {e["name"]: e for e in d["legs"]}
+    assert list(legs) == LEG_NAMES
+    n = 300000
+    for name, e in legs.items():
+        assert "error" not in e, e
+        assert e["avg_us"] > 0 and e["algorithmic_bytes"] > 0 and 0 < e["frac"] < 1.0, e
+        assert abs(e["frac"] - e["algorithmic_bytes"] / (e["avg_us"] * 1e-6) / 8e12) < 2e-3
+        assert e["traffic"] is None                 # --traffic off
+    c2 = legs["config2"]
+    assert c2["algorithmic_bytes"] == 56 * (1 << 20) and c2["launches"] == 200 and "11 buffer sets" in c2["protocol"]
+    assert c2["unrotated"]["avg_us"] > 0 and c2["double4"]["avg_us"] > 0 and c2["target_frac"] == 0.70
+    assert legs["config4_sph"]["algorithmic_bytes"] == 224 * n and legs["config4_union"]["algorithmic_bytes"] == 328 * n
+    for k in ("config4_sph", "config4_union"):
+        assert legs[k]["frames"] == 3 and legs[k]["value_GBps"] > 0 and legs[k]["target_fstype"] == "tmpfs"
+    c5 = legs["config5_read"]
+    assert c5["bit_exact"] is True and c5["file_to_hbm_GBps"] > 0 and c5["algorithmic_bytes"] == 56 * n
+    assert legs["gather_uniform"]["algorithmic_bytes"] == 60 * n == legs["gather_hilbert"]["algorithmic_bytes"]
+    assert d["legs_wall_s"] > 0
+
+
+def test_legs_measure_their_hbm_traffic():
+    """One FETCH_SIZE and one WRITE_SIZE pass over a child that launches every leg's kernels, the legs told apart by a
+    marker launch: the streaming legs move about their algorithmic bytes, the random gather moves several times its."""
+    d = run_bench("--no-cpu-baseline", "--no-stall-test", "--no-exchange-probe", legs=True)
+    if d["roofline"]["traffic"] is None:
+        pytest.skip("rocprofv3 not usable on this box")
+    legs = {e["name"]: e for e in d["legs"]}
+    assert d["legs_traffic_source"].startswith("live")
+    for k in ("config2", "config4_sph", "config4_union", "config5_read"):
+        e = legs[k]
+        assert e["traffic"] is not None, e
+        assert 0.9 < e["traffic_over_algorithmic"] < 1.35, e
+    assert legs["gather_uniform"]["traffic_over_algorithmic"] > legs["gather_hilbert"]["traffic_over_algorithmic"] * 0.9

@@ -66,9 +66,16 @@ def make_jobs(workload, N, gen):
                 (out(N, 3, f32), np.float32, 3, vel, 0, None, False),
                 (out(N, 1, i32), np.uint32, 1, tid, 0, None, False)]
         algo, moved = (24 + 24 + 4 + 28) * N, (32 + 32 + 4 + 28) * N
-    elif workload == "gather":            # tag order through a permutation
+    elif workload in ("gather", "gather_hilbert"):   # tag order through a permutation: uniformly random (adversarial),
+        # or lattice-order tags over Hilbert-curve memory order (what HOOMD's SFC sorter leaves; bench_legs.hilbert_order)
         pos, vel = rnd((N, 4), f32), rnd((N, 4), f32)
-        order = torch.randperm(N, generator=gen, device="cuda").to(i32); keep.append(order)
+        if workload == "gather":
+            order = torch.randperm(N, generator=gen, device="cuda").to(i32)
+        else:
+            sys.path.insert(0, ROOT)
+            import bench_legs
+            order = bench_legs.hilbert_order(N, torch)
+        keep.append(order)
         jobs = [(out(N, 3, f32), np.float32, 3, pos, 0, order, False),
                 (out(N, 3, f32), np.float32, 3, vel, 0, order, False)]
         algo, moved = (24 + 8 + 24) * N, (32 + 8 + 24) * N
