@@ -213,7 +213,8 @@ def probe_rccl_exchange(device, n=300, nbytes=512):
         from pgsd import _lib
         lib = _lib.lib
         uid = (ctypes.c_uint8 * 128)()
-        if lib.pgsd_comm_rccl_unique_id(uid) != 0 or lib.pgsd_comm_init_rccl(uid, 0, 1, int(device)) != 0:
+        import pgsd.dist as pdist
+        if lib.pgsd_comm_rccl_unique_id(uid) != 0 or pdist.init_rccl(bytes(uid), 0, 1, int(device)) != 0:
             print("bench.py: no RCCL exchange probe (%s)" % _lib.last_error(), file=sys.stderr)
             return None
         send = (ctypes.c_uint8 * nbytes)()

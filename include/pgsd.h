@@ -242,14 +242,6 @@ extern "C"
        size). */
     int pgsd_set_partition(struct pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks);
 
-    /* Batched mode only: with `on`, the host rows of pgsd_write_chunk(..., all == true, data) are BORROWED UNTIL
-       THE FRAME'S EXCHANGE instead of for the call -- the caller promises to leave them alone until the next
-       pgsd_end_frame / pgsd_flush / pgsd_frame_exchange / pgsd_close (the contract device sources have anyway).
-       Such a chunk then waits in the queue like every other instead of resolving it at once, and a frame costs
-       ONE exchange whatever mix of host and device chunks it holds.  (The reference's contract -- rows borrowed
-       for the call -- is the default; pgsd.fl turns this on where it holds the arrays itself.) */
-    int pgsd_set_deferred_rows(struct pgsd_handle* handle, int on);
-
     /* pgsd_read_chunk / pgsd_read_chunk_device on a writable handle flush first like the reference's (pgsd.c:2436
        -2537): collective, because a rank may read rows another rank wrote.  With `on`, reads are LOCAL: they wait
        for this rank's own asynchronous copies only and take no part in a collective -- for rows the caller knows to
@@ -261,16 +253,13 @@ extern "C"
        buffered small chunks only is not flushed by pgsd_end_frame (pgsd.c:1941-1950), and its chunks are not found
        by a local lookup until the next collective flush. */
     int pgsd_set_local_reads(struct pgsd_handle* handle, int on);
-    /* Perform the exchange now (collective; nothing is flushed): afterwards the queue is empty and the
-       handle's mirror is current.  No-op when nothing is queued. */
-    int pgsd_frame_exchange(struct pgsd_handle* handle);
-    /* Number of collectives (allgathers, barriers) this handle has issued on its communicator since it
-       was opened: the evidence behind "one collective per frame" (bench.py, tests). */
-    uint64_t pgsd_get_collective_count(struct pgsd_handle* handle);
-    /* What those allgathers cost the calling thread (wall clock around the communicator's allgather:
-       transport latency + the wait for the slowest rank): bench.py's `exchange_us`. */
+    /* Collectives of a handle: `collectives` = allgathers and barriers it has issued on its communicator since it
+       was opened (never reset: the evidence behind "one collective per frame"); the rest = what its allgathers
+       cost the calling thread (wall clock around the communicator's allgather: transport latency + the wait for
+       the slowest rank): bench.py's `exchange_us`. */
     struct pgsd_exchange_stats
         {
+        uint64_t collectives; /* since open */
         uint64_t count;   /* allgathers since open / last reset */
         double total_us;
         double max_us;
@@ -335,20 +324,18 @@ extern "C"
         void (*destroy)(void* ctx);
         };
 
-    /* install a caller-provided back end (the struct is copied) */
+    /* Install a back end as the process default: a caller-provided one (MPI, torch.distributed callbacks), or one
+       made by pgsd_comm_create_shm / pgsd_comm_create_rccl below.  The struct is copied and the default OWNS the
+       context from then on (its `destroy` runs when the default is replaced and the last handle opened on it is
+       closed): a communicator that was installed is not passed to pgsd_comm_release. */
     int pgsd_comm_set_default(const struct pgsd_comm* comm);
-    /* single rank (the state after library load) */
-    int pgsd_comm_init_self(void);
-    /* ranks of ONE node through a /dev/shm segment (process-shared barrier + slots) */
-    int pgsd_comm_init_shm(const char* name, int rank, int size);
-    /* PGSD_RANK / PGSD_NRANKS / PGSD_SHM_NAME, else RANK / WORLD_SIZE / MASTER_PORT
-       (torchrun), else self */
+    /* a /dev/shm communicator installed from the environment: PGSD_RANK / PGSD_NRANKS / PGSD_SHM_NAME, else
+       RANK / WORLD_SIZE / MASTER_PORT (torchrun), else single rank */
     int pgsd_comm_init_from_env(void);
-    /* RCCL over xGMI: `unique_id` is the 128-byte ncclUniqueId created by
+    /* RCCL over xGMI (pgsd_comm_create_rccl): `unique_id` is the 128-byte ncclUniqueId created by
        pgsd_comm_rccl_unique_id() on one rank and distributed by the caller.  Allgathers run
        as ncclAllGather on device buffers on a private HIP stream. */
     int pgsd_comm_rccl_unique_id(void* unique_id_128);
-    int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device);
     /* What one rank can know BEFORE the collective bootstrap above: librccl loads with the entry points used and
        `device` (-1: the current one) exists.  Callers let the ranks agree on it first, so that nobody waits inside
        ncclCommInitRank for a rank that could never have come.  An exchange on an RCCL communicator waits at most
@@ -356,18 +343,21 @@ extern "C"
        asynchronous error -- the communicator is aborted (ncclCommAbort), the call returns PGSD_ERROR_COMM and so
        does every later collective on it. */
     int pgsd_comm_rccl_available(int device);
+    /* back to a single rank (the state after library load) */
     int pgsd_comm_finalize(void);
     int pgsd_comm_rank(void);
     int pgsd_comm_size(void);
     int pgsd_comm_allgather(const void* send, void* recv, size_t bytes);
     int pgsd_comm_barrier(void);
 
-    /* Communicators that are NOT the process default: several ranks in ONE process (one thread per GPU, each
-       with a handle of its own), or independent groups of ranks side by side.  pgsd_comm_create_* fill in
-       `out` without installing anything; pgsd_create_and_open_on / pgsd_open_on open a file on such a
-       communicator (the struct is copied; the caller keeps the communicator alive until every handle opened
-       on it is closed, then lets it go with pgsd_comm_release).  Everything else is as with the default
-       communicator: the pgsd_* calls on the handle are collective over ITS communicator. */
+    /* Making communicators.  pgsd_comm_create_shm: ranks of ONE node through a /dev/shm segment (process-shared
+       barrier + slots); pgsd_comm_create_rccl: RCCL over xGMI.  Both fill in `out` without installing anything.
+       Either the caller installs it as the process default (pgsd_comm_set_default, which takes it over), or it
+       stays a communicator that is NOT the default: several ranks in ONE process (one thread per GPU, each
+       with a handle of its own), or independent groups of ranks side by side.  pgsd_create_and_open_on /
+       pgsd_open_on open a file on such a communicator (the struct is copied; the caller keeps the communicator
+       alive until every handle opened on it is closed, then lets it go with pgsd_comm_release).  Everything else
+       is as with the default communicator: the pgsd_* calls on the handle are collective over ITS communicator. */
     int pgsd_comm_create_shm(const char* name, int rank, int size, struct pgsd_comm* out);
     int pgsd_comm_create_rccl(const void* unique_id_128, int rank, int size, int device, struct pgsd_comm* out);
     void pgsd_comm_release(struct pgsd_comm* comm);
@@ -537,28 +527,21 @@ extern "C"
         };
     int pgsd_device_get_stats(struct pgsd_handle* handle, struct pgsd_device_stats* out, int reset);
 
-    /* Bare kernels, no file: pack into caller-provided device buffers on `stream`
-       (a hipStream_t passed as void*; NULL = the null stream).  Used by the parity tests and
-       by bench.py's roofline leg. */
-    struct pgsd_pack_job
-        {
-        void* dst;         /* device pointer, N*M elements of dst_type, 16-byte aligned */
-        uint32_t dst_type; /* enum pgsd_type */
-        uint32_t M;
-        struct pgsd_field_desc src;
-        };
-    /* kernel_ms (may be NULL): receives the time from the begin of the first to the end of the last kernel of the call
-       as the dispatches themselves stamp it (what rocprofv3 reports per kernel; no launch latency); the call then
-       synchronises `stream`.  Measurement only (tools/pack_bench.py). */
-    int pgsd_pack_fields(uint32_t n_jobs, const struct pgsd_pack_job* jobs, uint64_t N, void* stream, float* kernel_ms);
+    /* Stream compaction for filtered snapshots: out_index[k] = i for the k-th row whose flag byte is non-zero
+       (stable; device memory, room for N entries), *out_count (HOST memory) = number selected.  Wavefront
+       ballot/popcount scans + one cross-block pass on `stream` (a hipStream_t passed as void*; NULL = the null
+       stream); the scratch space is the library's (kept per device, grown on demand); the call returns when the
+       count is known, i.e. after synchronising `stream`. */
+    int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count, void* stream);
 
-    /* Stream compaction for filtered snapshots: out_index[k] = i for the k-th row whose
-       flag byte is non-zero (stable), *out_count (device uint64) = number selected.
-       Wavefront ballot/popcount scans + one cross-block pass. `workspace` must hold
-       pgsd_select_workspace_bytes(N) bytes. */
-    size_t pgsd_select_workspace_bytes(uint64_t N);
-    int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
-                         void* workspace, void* stream);
+    /* Device memory owned by the library, for callers that have no allocator of their own at hand (pgsd.fl /
+       pgsd.hoomd keep the references of the GPU-side elision, the rows of device reads and the index lists of
+       pgsd.fl.select_rows in it, so that the Python device path needs no tensor library): `bytes` bytes on
+       `device` (-1: the current one), 256-byte aligned.  `pattern` (may be NULL: contents undefined): host memory
+       of pattern_bytes bytes that is repeated over the whole buffer (a default value's rows; zeros).  NULL on
+       failure (pgsd_last_error_string).  pgsd_device_free takes what pgsd_device_alloc returned. */
+    void* pgsd_device_alloc(int device, size_t bytes, const void* pattern, size_t pattern_bytes);
+    int pgsd_device_free(int device, void* ptr);
 
     /* --- read side of the device path (restart files): file -> pinned slabs -> HBM -> unpack --- */
 
@@ -568,7 +551,7 @@ extern "C"
        needs equal element sizes).  Columns of the destination rows that no chunk writes are
        left untouched, so position.xyz and the type id can be restored into one Scalar4 array --
        unless fill_rest is set: then every column of the row that no chunk of the same launch
-       (pgsd_unpack_fields call / pgsd_device_wait_read) writes receives fill_bits, the bit pattern of
+       (pgsd_device_wait_read) writes receives fill_bits, the bit pattern of
        one destination element.  Velocity without a mass chunk thus restores as {vx, vy, vz, 1.0f}:
        ONE whole 16-byte row per particle instead of a 12-byte piece at a 16-byte stride. */
     struct pgsd_field_dst
@@ -599,25 +582,19 @@ extern "C"
                                const struct pgsd_field_dst* dst);
     int pgsd_device_wait_read(struct pgsd_handle* handle);
 
-    /* Bare unpack kernel: dense chunk rows already in device memory -> destination arrays. */
-    struct pgsd_unpack_job
-        {
-        const void* src;   /* device pointer, N*M elements of src_type, 16-byte aligned */
-        uint32_t src_type; /* enum pgsd_type of the chunk */
-        uint32_t M;
-        struct pgsd_field_dst dst;
-        };
-    int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job* jobs, uint64_t N, void* stream);
-
     /* 1 when a gfx950-capable HIP device is visible to this process */
     int pgsd_device_available(void);
 
     /* A closed handle of the default pipeline geometry PARKS what is dear to make -- two streams, up to four 16 MiB
        pinned slabs, the pinned arena of the small-frame path, up to four 256 MiB staging arenas in HBM (1 GiB), idle
        events -- for the next handle on the same device: at most two sets per process, held until the process ends
-       (PGSD_NO_PARKING in the environment: nothing is parked).  This call gives every parked set back to the runtime
-       now; returns the number of sets freed.  Not to be called while another thread opens or closes a handle. */
-    int pgsd_device_release_parked(void);
+       (PGSD_NO_PARKING in the environment: nothing is parked). */
+
+    /* The binary interface of this header.  Entry points that change their signature in place bump it; bindings
+       that resolve symbols at run time (ctypes, dlsym, the Cython module of pgsd.fl) compare it with the
+       PGSD_ABI_VERSION they were written against before the first call. */
+#define PGSD_ABI_VERSION 5u
+    uint32_t pgsd_abi_version(void);
 
 #ifdef __cplusplus
     }

@@ -384,16 +384,6 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_comm_init_self(void)
-    try
-    {
-    return comm_install(make_self());
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
-
 enum
     {
     SHM_RETRY = 1
@@ -551,20 +541,6 @@ static int shm_open_comm(const char* name, int rank, int size, pgsd_comm* out)
         }
     }
 
-extern "C" int pgsd_comm_init_shm(const char* name, int rank, int size)
-    try
-    {
-    if (!name || size < 1 || rank < 0 || rank >= size)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    if (size == 1)
-        return pgsd_comm_init_self();
-    return shm_open_comm(name, rank, size, nullptr);
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
-
 extern "C" int pgsd_comm_create_shm(const char* name, int rank, int size, struct pgsd_comm* out)
     try
     {
@@ -596,6 +572,16 @@ catch (...)
         pgsd_amd::abi_guard();
     }
 
+// ranks of one node through a /dev/shm segment, installed as the process default (pgsd_comm_init_from_env)
+static int install_shm(const char* name, int rank, int size)
+    {
+    if (!name || size < 1 || rank < 0 || rank >= size)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    if (size == 1)
+        return comm_install(make_self());
+    return shm_open_comm(name, rank, size, nullptr);
+    }
+
 extern "C" int pgsd_comm_init_from_env(void)
     try
     {
@@ -606,7 +592,7 @@ extern "C" int pgsd_comm_init_from_env(void)
         {
         // ranks started by one launcher share their parent: a name no other job of this user has
         std::string name = nm ? nm : std::string("pgsd_amd_ppid_") + std::to_string((long)getppid());
-        return pgsd_comm_init_shm(name.c_str(), atoi(r), atoi(n));
+        return install_shm(name.c_str(), atoi(r), atoi(n));
         }
     r = getenv("RANK");
     n = getenv("WORLD_SIZE");
@@ -614,9 +600,9 @@ extern "C" int pgsd_comm_init_from_env(void)
         {
         const char* port = getenv("MASTER_PORT");
         std::string name = std::string("pgsd_amd_") + (port ? port : "0");
-        return pgsd_comm_init_shm(name.c_str(), atoi(r), atoi(n));
+        return install_shm(name.c_str(), atoi(r), atoi(n));
         }
-    return pgsd_comm_init_self();
+    return comm_install(make_self());
     }
 catch (...)
     {

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <sched.h>
 #include <unistd.h>
 
@@ -50,8 +51,12 @@ struct RcclApi
 
 static RcclApi g_rccl;
 
+// guarded: reachable from pgsd_comm_rccl_available and from several thread-ranks of one process at once
+static std::mutex g_rccl_lock;
+
 static bool load_rccl()
     {
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
     if (g_rccl.lib)
         return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -330,18 +335,6 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" int pgsd_comm_init_rccl(const void* unique_id_128, int rank, int size, int device)
-    try
-    {
-    pgsd_comm pc;
-    int rc = rccl_open_comm(unique_id_128, rank, size, device, &pc);
-    return rc == PGSD_SUCCESS ? pgsd_comm_set_default(&pc) : rc;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
-
 extern "C" int pgsd_comm_create_rccl(const void* unique_id_128, int rank, int size, int device, struct pgsd_comm* out)
     try
     {
@@ -360,7 +353,7 @@ static int rccl_open_comm(const void* unique_id_128, int rank, int size, int dev
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (!pgsd_device_available())
         {
-        set_last_error("pgsd_comm_init_rccl: no HIP device visible");
+        set_last_error("pgsd_comm_create_rccl: no HIP device visible");
         return PGSD_ERROR_NO_DEVICE;
         }
     if (!load_rccl())
@@ -382,7 +375,7 @@ static int rccl_open_comm(const void* unique_id_128, int rank, int size, int dev
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
         {
-        set_last_error("pgsd_comm_init_rccl: cannot select device / create stream");
+        set_last_error("pgsd_comm_create_rccl: cannot select device / create stream");
         delete c;
         return PGSD_ERROR_DEVICE;
         }

@@ -677,6 +677,11 @@ class DevicePipeline
 
     // Packed bytes of staged (not yet committed) chunks against reference bytes in device memory: one kernel behind
     // the pack on the pack stream, one stream wait, the answers in pinned words the kernel wrote across PCIe.
+    int device() const
+        {
+        return m_cfg.device;
+        }
+
     int compare(int ticket, size_t first, size_t count, const void* const* ref, const uint64_t* ref_bytes, uint8_t* equal)
         {
         if (!m_ok)
@@ -706,11 +711,17 @@ class DevicePipeline
                     j.mode = c.job.dst_type == PGSD_TYPE_FLOAT ? CMP_F32 : c.job.dst_type == PGSD_TYPE_DOUBLE ? CMP_F64 : CMP_BYTES;
                     if (ref_bytes && ref_bytes[i] < bytes)
                         {
-                        // a reference shorter than the chunk repeats: whole 16-byte vectors, whole elements, and long
-                        // enough for the kernel's one-step wrap (256 vectors)
+                        // a reference shorter than the chunk repeats: whole 16-byte vectors, whole ROWS (a period that
+                        // cuts a row would be compared out of phase from the second repetition on), and long enough for
+                        // the kernel's one-step wrap (256 vectors)
                         const uint64_t p = ref_bytes[i];
-                        if (p < 4096 || p % 16 != 0 || p % sizeof_type(c.job.dst_type) != 0 || ((uintptr_t)ref[i] & 15) != 0)
+                        if (p < 4096 || p % 16 != 0 || p % ((uint64_t)c.job.M * sizeof_type(c.job.dst_type)) != 0
+                            || ((uintptr_t)ref[i] & 15) != 0)
+                            {
+                            set_last_error("a repeating reference must be 16-byte aligned, at least 4096 bytes and a multiple "
+                                           "of 16 bytes and of whole rows");
                             return PGSD_ERROR_INVALID_ARGUMENT;
+                            }
                         j.period = p;
                         }
                     jobs.push_back(j);
@@ -1691,6 +1702,11 @@ DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, bo
 void device_pipeline_destroy(DevicePipeline* p)
     {
     delete p;
+    }
+
+int device_pipeline_device(DevicePipeline* p)
+    {
+    return p ? p->device() : -1;
     }
 
 int device_pipeline_submit(DevicePipeline* p, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err)

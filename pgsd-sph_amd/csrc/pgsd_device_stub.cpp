@@ -14,6 +14,7 @@ DevicePipeline* device_pipeline_create(const pgsd_device_config&, int, bool, std
     return nullptr;
     }
 void device_pipeline_destroy(DevicePipeline*) { }
+int device_pipeline_device(DevicePipeline*) { return -1; }
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_stage(DevicePipeline*, std::vector<DeviceChunk>&, uint64_t, int*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
 int device_pipeline_commit(DevicePipeline*, int, size_t, long long, void*, std::string*) { return PGSD_ERROR_NO_DEVICE; }
@@ -32,7 +33,6 @@ void device_pipeline_stats(DevicePipeline*, pgsd_device_stats*, int) { }
 
 extern "C" int pgsd_device_available(void) { return 0; }
 extern "C" int pgsd_comm_rccl_unique_id(void*) { return PGSD_ERROR_NO_DEVICE; }
-extern "C" int pgsd_comm_init_rccl(const void*, int, int, int) { return PGSD_ERROR_NO_DEVICE; }
 extern "C" int pgsd_comm_create_rccl(const void*, int, int, int, struct pgsd_comm*) { return PGSD_ERROR_NO_DEVICE; }
 extern "C" int pgsd_comm_rccl_available(int) { return PGSD_ERROR_NO_DEVICE; }
 extern "C" int pgsd_device_release_parked(void) { return 0; }

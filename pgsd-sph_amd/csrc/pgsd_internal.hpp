@@ -3,6 +3,7 @@
 #define PGSD_INTERNAL_HPP
 
 #include "pgsd.h"
+#include "pgsd_private.h"
 
 #include <cstdint>
 #include <sched.h>
@@ -105,6 +106,7 @@ struct DeviceChunk
     };
 DevicePipeline* device_pipeline_create(const pgsd_device_config& cfg, int fd, bool shared_file, std::string* err);
 void device_pipeline_destroy(DevicePipeline*);
+int device_pipeline_device(DevicePipeline*); // the HIP device the pipeline runs on
 // one fused pack launch for `chunks` (all share N), then async copy + write of each
 int device_pipeline_submit(DevicePipeline*, std::vector<DeviceChunk>& chunks, uint64_t N, std::string* err);
 // the same in two steps: pack now (one fused launch, returns a ticket), say later where chunk `index` of the

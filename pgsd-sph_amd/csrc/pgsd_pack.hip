@@ -32,6 +32,7 @@
 // of chunks in the golden files.
 #include "pgsd_internal.hpp"
 #include "pgsd_pack.hpp"
+#include "pgsd_private.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -41,6 +42,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace pgsd_amd
@@ -1544,6 +1547,88 @@ static void launch_tiles(bool prefetch, int mode, unsigned blocks, size_t lds_by
 #undef TILES_LAUNCH
     }
 
+// ---- tuning knobs: the PGSD_PACK_* / PGSD_UNPACK_* variables of the sweeps in tools/ (pack_bench.py, unpack_bench.py).
+// Read ONCE, when the first launch needs them; pgsd_reload_tuning() (pgsd_private.h) reads them again for tools
+// that A/B variants inside one process.  Defaults come from measurements on MI355X (profiles/).
+struct PackTuning
+    {
+    int rows_t = 0, rows_u = 0;           // PGSD_PACK_ROWS_CFG "<threads>x<rows per lane>" (0: by size)
+    bool pack_tiles = false;              // PGSD_PACK_KERNEL=tiles: the LDS-tiled kernel for everything (A/B, tests)
+    uint64_t per_cu = 4;                  // PGSD_PACK_BLOCKS_PER_CU
+    uint32_t tile_cap = 1024;             // PGSD_PACK_TILE
+    size_t lds_budget = PACK_LDS_BYTES;   // PGSD_PACK_LDS_KB
+    int prefetch = -1;                    // PGSD_PACK_PREFETCH (-1: by size)
+    int unrows_t = 0, unrows_u = 0;       // PGSD_UNPACK_ROWS_CFG (0: the default 64x2)
+    uint32_t unpack_tile_cap = 0;         // PGSD_UNPACK_TILE (0: by size)
+    uint64_t unpack_per_cu = 8;           // PGSD_UNPACK_BLOCKS_PER_CU
+    bool unpack_tiles = false;            // PGSD_UNPACK_KERNEL=tiles
+    };
+
+static std::mutex g_tuning_lock;
+static bool g_tuning_loaded = false;
+static PackTuning g_tuning;
+
+static PackTuning read_tuning()
+    {
+    PackTuning t;
+    if (const char* e = getenv("PGSD_PACK_ROWS_CFG"))
+        {
+        // only the instantiated pairs (launch_rows below): the grid is sized from T x U, so a pair the
+        // dispatcher does not know would pack too few rows per block and leave a part of every chunk unwritten
+        int a = 0, u = 0;
+        const bool known = sscanf(e, "%dx%d", &a, &u) == 2
+                           && ((a == 64 && u == 2) || (a == 128 && (u == 1 || u == 2))
+                               || (a == 256 && (u == 1 || u == 2 || u == 4 || u == 8)) || (a == 512 && (u == 2 || u == 4)));
+        if (known)
+            t.rows_t = a, t.rows_u = u;
+        else
+            fprintf(stderr, "pgsd_amd: PGSD_PACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2 256x4 256x8 512x2 512x4: ignored\n", e);
+        }
+    if (const char* e = getenv("PGSD_PACK_KERNEL"))
+        t.pack_tiles = strcmp(e, "tiles") == 0;
+    if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
+        t.per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : t.per_cu;
+    if (const char* e = getenv("PGSD_PACK_TILE"))
+        t.tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : t.tile_cap;
+    if (const char* e = getenv("PGSD_PACK_LDS_KB"))
+        t.lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : t.lds_budget;
+    if (const char* e = getenv("PGSD_PACK_PREFETCH"))
+        t.prefetch = atoi(e);
+    if (const char* e = getenv("PGSD_UNPACK_ROWS_CFG"))
+        {
+        int a = 0, u = 0;
+        if (sscanf(e, "%dx%d", &a, &u) == 2
+            && ((a == 64 && u == 2) || (a == 128 && (u == 1 || u == 2)) || (a == 256 && (u == 1 || u == 2))))
+            t.unrows_t = a, t.unrows_u = u;
+        else
+            fprintf(stderr, "pgsd_amd: PGSD_UNPACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2: ignored\n", e);
+        }
+    if (const char* e = getenv("PGSD_UNPACK_TILE"))
+        t.unpack_tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : 0;
+    if (const char* e = getenv("PGSD_UNPACK_BLOCKS_PER_CU"))
+        t.unpack_per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : t.unpack_per_cu;
+    if (const char* e = getenv("PGSD_UNPACK_KERNEL"))
+        t.unpack_tiles = strcmp(e, "tiles") == 0;
+    return t;
+    }
+
+static PackTuning tuning()
+    {
+    std::lock_guard<std::mutex> guard(g_tuning_lock);
+    if (!g_tuning_loaded)
+        {
+        g_tuning = read_tuning();
+        g_tuning_loaded = true;
+        }
+    return g_tuning;
+    }
+
+void reload_pack_tuning()
+    {
+    std::lock_guard<std::mutex> guard(g_tuning_lock);
+    g_tuning_loaded = false;
+    }
+
 // ---- row-per-lane launches
 struct RowsCfg
     {
@@ -1557,24 +1642,9 @@ static RowsCfg rows_config(uint64_t N, uint32_t n_groups)
     // (10 M particles, HOOMD layout: 94.8 us against 106.5 us for the LDS-tiled kernel); a launch of one
     // or two arrays below 2 M rows does better with half as many, fatter workgroups
     RowsCfg c = (N < (2u << 20) && n_groups <= 2) ? RowsCfg {256, 4} : RowsCfg {256, 2};
-    if (const char* e = getenv("PGSD_PACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
-        {
-        // only the instantiated pairs (launch_rows below): the grid is sized from T x U, so a pair the
-        // dispatcher does not know would pack too few rows per block and leave a part of every chunk unwritten
-        int t = 0, u = 0;
-        const bool known = sscanf(e, "%dx%d", &t, &u) == 2
-                           && ((t == 64 && u == 2) || (t == 128 && (u == 1 || u == 2))
-                               || (t == 256 && (u == 1 || u == 2 || u == 4 || u == 8)) || (t == 512 && (u == 2 || u == 4)));
-        if (known)
-            c = RowsCfg {t, u};
-        else
-            {
-            static bool warned = false;
-            if (!warned)
-                fprintf(stderr, "pgsd_amd: PGSD_PACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2 256x4 256x8 512x2 512x4: ignored\n", e);
-            warned = true;
-            }
-        }
+    const PackTuning t = tuning();
+    if (t.rows_t)
+        c = RowsCfg {t.rows_t, t.rows_u};
     return c;
     }
 
@@ -1687,8 +1757,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         K_TILES
         } kernel
         = K_ROWS;
-    if (const char* e = getenv("PGSD_PACK_KERNEL")) // "tiles": the LDS-tiled kernel for everything (A/B, tests)
-        kernel = strcmp(e, "tiles") == 0 ? K_TILES : K_ROWS;
+    const PackTuning tune = tuning();
+    if (tune.pack_tiles)
+        kernel = K_TILES;
 
     // 1. the row-per-lane kernel takes every job it can: one launch per class of source-row width (a
     //    compile-time parameter), dense same-type arrays ride along in any launch; up to ROWS_MAX_GROUPS
@@ -1867,15 +1938,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
             }
         if (!any)
             break;
-        uint64_t per_cu = 4;
-        uint32_t tile_cap = 1024;
-        if (const char* e = getenv("PGSD_PACK_BLOCKS_PER_CU"))
-            per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
-        if (const char* e = getenv("PGSD_PACK_TILE"))
-            tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
-        size_t lds_budget = PACK_LDS_BYTES;
-        if (const char* e = getenv("PGSD_PACK_LDS_KB"))
-            lds_budget = (size_t)atoi(e) > 0 ? (size_t)atoi(e) << 10 : lds_budget;
+        const uint64_t per_cu = tune.per_cu;
+        const uint32_t tile_cap = tune.tile_cap;
+        const size_t lds_budget = tune.lds_budget;
         // tile: as many rows as the widest source row allows (power of two in [16, tile_cap]);
         // consecutive source arrays then share a batch while their tiles fit the budget
         uint32_t tile = 16;
@@ -1915,9 +1980,7 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         for (uint32_t k = 0; k < args.n_groups; k++)
             prefetch = prefetch && args.g[k].order == nullptr
                        && (size_t)tile * args.g[k].rowbytes <= (size_t)PF_VECS * PACK_THREADS * 16;
-        int want = -1; // -1: by size
-        if (const char* e = getenv("PGSD_PACK_PREFETCH"))
-            want = atoi(e);
+        const int want = tune.prefetch; // -1: by size
         if (want == 0 || (want < 0 && args.n_tiles > 2 * blocks))
             prefetch = false;
         launches.push_back(
@@ -1949,20 +2012,9 @@ static void launch_unrows(const UnrowsPlan& p, uint64_t N, hipStream_t stream)
     // measured (profiles/r02_lab_unpack.jsonl, r02_unpack_rows_final.jsonl): thin workgroups; 64 x 2 rows
     // 102.4-103.0 us, 128 x 1 104.6-105.0 us, 256 x 2 105.9-106.0 us (10 M particles, stream events)
     int T = 64, U = 2;
-    if (const char* e = getenv("PGSD_UNPACK_ROWS_CFG")) // "<threads>x<rows per lane>", tuning sweeps
-        {
-        int t = 0, u = 0;
-        if (sscanf(e, "%dx%d", &t, &u) == 2
-            && ((t == 64 && u == 2) || (t == 128 && (u == 1 || u == 2)) || (t == 256 && (u == 1 || u == 2))))
-            T = t, U = u;
-        else
-            {
-            static bool warned = false;
-            if (!warned)
-                fprintf(stderr, "pgsd_amd: PGSD_UNPACK_ROWS_CFG=%s is not one of 64x2 128x1 128x2 256x1 256x2: ignored\n", e);
-            warned = true;
-            }
-        }
+    const PackTuning tune = tuning();
+    if (tune.unrows_t)
+        T = tune.unrows_t, U = tune.unrows_u;
     UnrowsArgs a = p.args;
     a.n_blocks = (N + (uint64_t)T * U - 1) / ((uint64_t)T * U);
     const dim3 grid((unsigned)a.n_blocks, a.n_groups);
@@ -2056,10 +2108,10 @@ static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, 
     // to fill the chip twice keep the larger tile
     uint32_t tile = 16, tile_cap = N > (1ull << 21) ? 512 : 1024;
     uint64_t per_cu = 8;
-    if (const char* e = getenv("PGSD_UNPACK_TILE")) // tuning sweeps (tools/unpack_bench.py)
-        tile_cap = (uint32_t)atoi(e) >= 16 ? (uint32_t)atoi(e) : tile_cap;
-    if (const char* e = getenv("PGSD_UNPACK_BLOCKS_PER_CU"))
-        per_cu = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_cu;
+    const PackTuning tune = tuning(); // tuning sweeps (tools/unpack_bench.py)
+    if (tune.unpack_tile_cap)
+        tile_cap = tune.unpack_tile_cap;
+    per_cu = tune.unpack_per_cu;
     while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * sum_rowbytes <= UNPACK_LDS_BYTES)
         tile <<= 1;
     args.tile_rows = tile;
@@ -2129,8 +2181,7 @@ int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipS
     //    restored from f32 chunks) fed by one or two chunks of 4-byte elements on disjoint columns, no
     //    scatter index; plus dense same-type arrays (the chunk IS the array).  One launch per conversion
     //    class; everything else goes to the LDS-tiled kernel below.
-    const char* force = getenv("PGSD_UNPACK_KERNEL");
-    if (N < (1ull << 31) && !(force && strcmp(force, "tiles") == 0))
+    if (N < (1ull << 31) && !tuning().unpack_tiles)
         {
         std::vector<bool> taken(all.size(), false);
         for (int f64 = 0; f64 < 2; f64++)
@@ -2367,39 +2418,68 @@ catch (...)
         return pgsd_amd::abi_guard();
     }
 
-extern "C" size_t pgsd_select_workspace_bytes(uint64_t N)
-    try
+// scratch space of pgsd_select_rows: the library's, one per device, grown on demand (a call holds the lock: it ends
+// with a stream synchronisation anyway)
+namespace
     {
-    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
-    if (n_blocks == 0)
-        n_blocks = 1;
-    // block_counts (u32) rounded to 8 bytes + block_offsets (u64)
-    return (size_t)(((n_blocks * 4 + 7) & ~7ull) + n_blocks * 8);
-    }
-catch (...)
+struct SelectScratch
     {
-        pgsd_amd::abi_guard();
-        return 0;
-    }
+    void* dev = nullptr;
+    size_t cap = 0;
+    uint64_t* host_count = nullptr; // pinned
+    };
+std::mutex g_select_lock;
+std::map<int, SelectScratch> g_select_scratch;
+    } // namespace
 
-extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count,
-                                void* workspace, void* stream_)
+extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count_host, void* stream_)
     try
     {
-    if (!out_count || !workspace || (N > 0 && (!flags || !out_index)) || N >= (1ull << 32))
+    if (!out_count_host || (N > 0 && (!flags || !out_index)) || N >= (1ull << 32))
         return PGSD_ERROR_INVALID_ARGUMENT;
     if (!pgsd_device_available())
         {
         set_last_error("pgsd_select_rows: no HIP device visible (the HIP path has no CPU fallback)");
         return PGSD_ERROR_NO_DEVICE;
         }
-    hipStream_t stream = (hipStream_t)stream_;
-    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
     if (N == 0)
         {
-        (void)hipMemsetAsync(out_count, 0, sizeof(uint64_t), stream);
+        *out_count_host = 0;
+        return PGSD_SUCCESS;
         }
-    else
+    std::lock_guard<std::mutex> guard(g_select_lock);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return PGSD_ERROR_DEVICE;
+    SelectScratch& sc = g_select_scratch[device];
+        {
+        uint64_t nb = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
+        // the count (u64) + block_counts (u32) rounded to 8 bytes + block_offsets (u64)
+        const size_t need = 8 + (size_t)(((nb * 4 + 7) & ~7ull) + nb * 8);
+        if (need > sc.cap)
+            {
+            if (sc.dev)
+                (void)hipFree(sc.dev);
+            sc.dev = nullptr;
+            sc.cap = 0;
+            const size_t cap = std::max<size_t>(need * 2, 1u << 16);
+            if (hipMalloc(&sc.dev, cap) != hipSuccess)
+                {
+                set_last_error("pgsd_select_rows: cannot allocate the scratch space");
+                return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
+                }
+            sc.cap = cap;
+            }
+        if (!sc.host_count && hipHostMalloc((void**)&sc.host_count, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess)
+            {
+            set_last_error("pgsd_select_rows: cannot allocate pinned memory");
+            return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
+            }
+        }
+    uint64_t* out_count = (uint64_t*)sc.dev;
+    void* workspace = (char*)sc.dev + 8;
+    hipStream_t stream = (hipStream_t)stream_;
+    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
         {
         uint32_t* block_counts = (uint32_t*)workspace;
         uint64_t* block_offsets = (uint64_t*)((char*)workspace + ((n_blocks * 4 + 7) & ~7ull));
@@ -2414,6 +2494,126 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
     if (e != hipSuccess)
         {
         set_last_error(std::string("select kernel launch failed: ") + hipGetErrorString(e));
+        return PGSD_ERROR_DEVICE;
+        }
+    e = hipMemcpyAsync(sc.host_count, out_count, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);
+    if (e != hipSuccess)
+        {
+        set_last_error(std::string("pgsd_select_rows: ") + hipGetErrorString(e));
+        return PGSD_ERROR_DEVICE;
+        }
+    *out_count_host = *sc.host_count;
+    return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" void pgsd_reload_tuning(void)
+    try
+    {
+    pgsd_amd::reload_pack_tuning();
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+    }
+
+extern "C" uint32_t pgsd_abi_version(void)
+    {
+    return PGSD_ABI_VERSION;
+    }
+
+// Device memory owned by the library (include/pgsd.h): what pgsd.fl / pgsd.hoomd keep elision references, device
+// reads and index lists in, so that the Python device path needs no tensor library.
+extern "C" void* pgsd_device_alloc(int device, size_t bytes, const void* pattern, size_t pattern_bytes)
+    try
+    {
+    if (!pgsd_device_available())
+        {
+        set_last_error("pgsd_device_alloc: no HIP device visible (the HIP path has no CPU fallback)");
+        return nullptr;
+        }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (device >= 0 && device != prev && hipSetDevice(device) != hipSuccess)
+        {
+        set_last_error("pgsd_device_alloc: no device " + std::to_string(device));
+        return nullptr;
+        }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+    if (e == hipSuccess && pattern && pattern_bytes > 0 && bytes > 0)
+        {
+        // the pattern repeated over a host image of at most 1 MiB (a multiple of the pattern), copied piecewise
+        const size_t reps = std::max<size_t>(1, std::min<size_t>((1u << 20) / pattern_bytes, (bytes + pattern_bytes - 1) / pattern_bytes));
+        std::vector<char> img(reps * pattern_bytes);
+        for (size_t r = 0; r < reps; r++)
+            memcpy(img.data() + r * pattern_bytes, pattern, pattern_bytes);
+        for (size_t at = 0; at < bytes && e == hipSuccess; at += img.size())
+            e = hipMemcpy((char*)p + at, img.data(), std::min(img.size(), bytes - at), hipMemcpyHostToDevice);
+        }
+    if (e != hipSuccess)
+        {
+        set_last_error(std::string("pgsd_device_alloc: ") + hipGetErrorString(e));
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        }
+    if (device >= 0 && prev >= 0 && device != prev)
+        (void)hipSetDevice(prev);
+    return p;
+    }
+catch (...)
+    {
+        pgsd_amd::abi_guard();
+        return nullptr;
+    }
+
+extern "C" int pgsd_device_free(int device, void* ptr)
+    try
+    {
+    if (!ptr)
+        return PGSD_SUCCESS;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (device >= 0 && device != prev)
+        (void)hipSetDevice(device);
+    const hipError_t e = hipFree(ptr);
+    if (device >= 0 && prev >= 0 && device != prev)
+        (void)hipSetDevice(prev);
+    if (e != hipSuccess)
+        {
+        set_last_error(std::string("pgsd_device_free: ") + hipGetErrorString(e));
+        return PGSD_ERROR_DEVICE;
+        }
+    return PGSD_SUCCESS;
+    }
+catch (...)
+    {
+        return pgsd_amd::abi_guard();
+    }
+
+extern "C" int pgsd_device_copy(int device, void* dst, const void* src, size_t bytes)
+    try
+    {
+    if (bytes == 0)
+        return PGSD_SUCCESS;
+    if (!dst || !src)
+        return PGSD_ERROR_INVALID_ARGUMENT;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (device >= 0 && device != prev)
+        (void)hipSetDevice(device);
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDefault); // either side may be host memory
+    if (device >= 0 && prev >= 0 && device != prev)
+        (void)hipSetDevice(prev);
+    if (e != hipSuccess)
+        {
+        set_last_error(std::string("pgsd_device_copy: ") + hipGetErrorString(e));
         return PGSD_ERROR_DEVICE;
         }
     return PGSD_SUCCESS;

@@ -4,6 +4,7 @@
 #define PGSD_PACK_HPP
 
 #include "pgsd.h"
+#include "pgsd_private.h"
 
 #include <hip/hip_runtime_api.h>
 

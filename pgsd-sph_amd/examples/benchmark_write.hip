@@ -102,7 +102,10 @@ int main(int argc, char** argv)
                         r == rank ? ": " : "", r == rank ? pgsd_last_error_string() : "");
                 return 1;
                 }
-        CHECK(pgsd_comm_init_rccl(all.data(), rank, P, rank % ndev));
+        // make the RCCL communicator and install it as the process default (the default takes it over)
+        struct pgsd_comm rccl;
+        CHECK(pgsd_comm_create_rccl(all.data(), rank, P, rank % ndev, &rccl));
+        CHECK(pgsd_comm_set_default(&rccl));
         comm_name = "rccl";
         }
 
@@ -199,7 +202,9 @@ int main(int argc, char** argv)
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     struct pgsd_device_stats st;
     pgsd_device_get_stats(&h, &st, 0);
-    const unsigned long long collectives = (unsigned long long)pgsd_get_collective_count(&h);
+    struct pgsd_exchange_stats xs;
+    pgsd_get_exchange_stats(&h, &xs, 0);
+    const unsigned long long collectives = (unsigned long long)xs.collectives;
     CHECK(pgsd_close(&h));
     if (rank == 0)
         {

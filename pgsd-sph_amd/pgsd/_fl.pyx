@@ -29,6 +29,10 @@ from . import _lib
 
 logger = logging.getLogger('pgsd.fl')
 
+if C.pgsd_abi_version() != C.PGSD_ABI_VERSION:
+    raise ImportError("pgsd/_fl was built against ABI version %d of include/pgsd.h, libpgsd_amd.so has %d: rebuild "
+                      "(`make -C pgsd-sph_amd/csrc`)" % (C.PGSD_ABI_VERSION, C.pgsd_abi_version()))
+
 _NP_TO_PGSD = {
     numpy.dtype('uint8'): 1, numpy.dtype('uint16'): 2, numpy.dtype('uint32'): 3, numpy.dtype('uint64'): 4,
     numpy.dtype('int8'): 5, numpy.dtype('int16'): 6, numpy.dtype('int32'): 7, numpy.dtype('int64'): 8,
@@ -279,39 +283,220 @@ def _is_device_array(x):
         return False
 
 
+cdef class DeviceBuffer:
+    """Device memory owned by ``libpgsd_amd.so`` (``pgsd_device_alloc``), described through
+    ``__cuda_array_interface__`` (version 3) so that PyTorch, CuPy, Numba or HOOMD take it without a copy
+    (``torch.as_tensor(buf, device='cuda')``).  What :mod:`pgsd.fl` / :mod:`pgsd.hoomd` keep in HBM themselves lives
+    here -- references of the GPU-side elision, rows of device reads when no tensor library is importable, index
+    lists of :func:`select_rows` -- so the Python device path needs no tensor library: torch is an optional
+    PRODUCER of source arrays, never a requirement.
+
+    Args:
+        shape: tuple of ints (or an int).
+        dtype: numpy dtype of an element.
+        device (int): HIP device ordinal (-1: the current one).
+        pattern: optional host array / bytes repeated over the whole buffer (rows of a default value).
+    """
+    cdef public object dtype, shape, strides, base
+    cdef public Py_ssize_t nbytes
+    cdef public int device
+    cdef uintptr_t _ptr
+    cdef bint _owner
+
+    def __init__(self, shape, dtype=numpy.uint8, device=-1, pattern=None):
+        self.dtype = numpy.dtype(dtype)
+        self.shape = (int(shape),) if isinstance(shape, (int, numpy.integer)) else tuple(int(x) for x in shape)
+        self.strides = None
+        self.base = None
+        self.device = int(device)
+        n = 1
+        for x in self.shape:
+            n *= x
+        self.nbytes = n * self.dtype.itemsize
+        cdef size_t c_bytes = self.nbytes, c_pat = 0
+        cdef const void* c_ptr = NULL
+        cdef int c_dev = self.device
+        cdef void* got
+        pat = None
+        if pattern is not None:
+            pat = numpy.ascontiguousarray(pattern).view(numpy.uint8).reshape(-1)
+            if pat.size > 0:
+                c_pat = pat.size
+                c_ptr = <const void*><uintptr_t>pat.ctypes.data
+        with nogil:
+            got = C.pgsd_device_alloc(c_dev, c_bytes, c_ptr, c_pat)
+        if got == NULL:
+            msg = C.pgsd_last_error_string()
+            raise RuntimeError("pgsd_device_alloc(%d bytes) failed: %s"
+                               % (self.nbytes, msg.decode('utf-8', 'replace') if msg != NULL else ''))
+        self._ptr = <uintptr_t>got
+        self._owner = True
+
+    def __dealloc__(self):
+        if self._owner and self._ptr != 0:
+            C.pgsd_device_free(self.device, <void*>self._ptr)
+            self._ptr = 0
+
+    @property
+    def ptr(self):
+        return int(self._ptr)
+
+    def data_ptr(self):
+        return int(self._ptr)
+
+    def numel(self):
+        n = 1
+        for x in self.shape:
+            n *= x
+        return n
+
+    def element_size(self):
+        return self.dtype.itemsize
+
+    def is_contiguous(self):
+        return self.strides is None
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 1
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (int(self._ptr), False), 'version': 3,
+                'strides': self.strides}
+
+    def view(self, dtype=None, shape=None, strides=None, offset_bytes=0):
+        """Another description of (a part of) the same memory; the view keeps this buffer alive.  ``strides`` in
+        bytes (0 repeats a row: the default rows of :meth:`pgsd.hoomd.HOOMDTrajectory.read_frame_device`)."""
+        cdef DeviceBuffer v = DeviceBuffer.__new__(DeviceBuffer)
+        v.dtype = numpy.dtype(dtype) if dtype is not None else self.dtype
+        if shape is None:
+            if self.nbytes % v.dtype.itemsize != 0:
+                raise ValueError("the buffer is not a whole number of such elements")
+            shape = ((self.nbytes - int(offset_bytes)) // v.dtype.itemsize,)
+        v.shape = (int(shape),) if isinstance(shape, (int, numpy.integer)) else tuple(int(x) for x in shape)
+        v.strides = tuple(int(x) for x in strides) if strides is not None else None
+        n = 1
+        for x in v.shape:
+            n *= x
+        # the bytes the view can reach must lie inside this buffer
+        if v.strides is None:
+            reach = n * v.dtype.itemsize
+        else:
+            reach = v.dtype.itemsize if n > 0 else 0
+            for x, st in zip(v.shape, v.strides):
+                reach += (x - 1) * st if x > 0 else 0
+        if offset_bytes < 0 or int(offset_bytes) + reach > self.nbytes:
+            raise ValueError("the view does not fit the buffer")
+        v.nbytes = n * v.dtype.itemsize
+        v.device = self.device
+        v.base = self
+        v._ptr = self._ptr + <uintptr_t>int(offset_bytes)
+        v._owner = False
+        return v
+
+    def clone(self):
+        """A buffer of its own with the same (dense) contents: one device-to-device copy."""
+        if self.strides is not None:
+            raise ValueError("only dense buffers are cloned")
+        cdef DeviceBuffer c = DeviceBuffer(self.shape, self.dtype, self.device)
+        cdef int rc, dev = self.device
+        cdef size_t n = self.nbytes
+        cdef uintptr_t d = c._ptr, s = self._ptr
+        with nogil:
+            rc = C.pgsd_device_copy(dev, <void*>d, <const void*>s, n)
+        _raise_on_error(rc, "DeviceBuffer.clone")
+        return c
+
+    def to_host(self):
+        """The contents as a numpy array (one device-to-host copy; dense buffers only)."""
+        if self.strides is not None:
+            raise ValueError("only dense buffers are copied to the host")
+        out = numpy.empty(self.shape, dtype=self.dtype)
+        cdef int rc, dev = self.device
+        cdef size_t n = self.nbytes
+        cdef uintptr_t d = out.ctypes.data, s = self._ptr
+        if n:
+            with nogil:
+                rc = C.pgsd_device_copy(dev, <void*>d, <const void*>s, n)
+            _raise_on_error(rc, "DeviceBuffer.to_host")
+        return out
+
+
+def _device_memory(x, what="array"):
+    """(address, bytes) of a DENSE array in GPU memory: a :class:`DeviceBuffer`, a torch GPU tensor or any object with
+    ``__cuda_array_interface__``."""
+    if isinstance(x, DeviceBuffer):
+        if not x.is_contiguous():
+            raise ValueError("%s must be dense" % what)
+        return x.ptr, int(x.nbytes)
+    if _is_device_tensor(x):
+        if not x.is_contiguous():
+            raise ValueError("%s must be a contiguous GPU tensor" % what)
+        return int(x.data_ptr()), int(x.numel() * x.element_size())
+    iface = getattr(x, '__cuda_array_interface__', None) if not hasattr(x, 'data_ptr') else None
+    if not isinstance(iface, dict):
+        raise ValueError("%s must live in GPU memory (DeviceBuffer, torch GPU tensor or __cuda_array_interface__)" % what)
+    dt = numpy.dtype(iface['typestr'])
+    shape = tuple(int(v) for v in iface['shape'])
+    n = 1
+    for v in shape:
+        n *= v
+    strides = iface.get('strides')
+    if strides is not None:
+        expect, acc = [], dt.itemsize
+        for v in reversed(shape):
+            expect.append(acc)
+            acc *= v
+        if n > 0 and tuple(int(v) for v in strides) != tuple(reversed(expect)):
+            raise ValueError("%s must be dense (C-contiguous)" % what)
+    return (int(iface['data'][0]) if n > 0 else 0), n * dt.itemsize
+
+
 def select_rows(flags):
     """Stream compaction on the GPU for filtered snapshots.
 
     Args:
-        flags: uint8 / bool torch GPU tensor of length N; non-zero = keep the particle.
+        flags: uint8 / bool array of length N in GPU memory (torch GPU tensor, :class:`DeviceBuffer` or any
+            ``__cuda_array_interface__`` object of one-byte elements); non-zero = keep the particle.
 
     Returns:
-        ``(index, count)``: ``index`` is an int32 GPU tensor whose first ``count`` entries are the
-        kept rows in ascending order (usable as ``order=`` of :meth:`DeviceField.from_tensor`);
-        ``count`` (int) is this rank's number of rows, i.e. what goes into the row-count allgather
+        ``(index, count)``: ``index`` holds the kept rows in ascending order as 32-bit integers (usable as
+        ``order=`` of :meth:`DeviceField.from_tensor` / :meth:`DeviceField.from_device_array`) -- an int32 GPU tensor
+        of ``count`` entries when ``flags`` is a torch tensor, a :class:`DeviceBuffer` view otherwise; ``count``
+        (int) is this rank's number of rows, i.e. what goes into the row-count allgather
         (``pgsd.dist.partition_rows``) that fixes every rank's file offsets.
 
     Wave-level ballot/popcount scans produce per-workgroup counts, one workgroup scans them
-    into offsets, a scatter pass writes the indices (pgsd_select_rows in the C ABI).
+    into offsets, a scatter pass writes the indices (pgsd_select_rows in the C ABI; the scratch space is the
+    library's).
     """
-    import torch
-    if not _is_device_tensor(flags):
-        raise ValueError("flags must be a torch GPU tensor")
-    f8 = flags.contiguous().view(torch.uint8) if flags.dtype in (torch.bool, torch.uint8, torch.int8) \
-        else (flags != 0).to(torch.uint8)
-    cdef uint64_t n = int(f8.numel())
-    index = torch.empty((max(n, 1),), dtype=torch.int32, device=f8.device)
-    count = torch.zeros((1,), dtype=torch.int64, device=f8.device)
-    ws = torch.empty((max(int(C.pgsd_select_workspace_bytes(n)), 16),), dtype=torch.uint8, device=f8.device)
-    cdef uintptr_t stream = torch.cuda.current_stream().cuda_stream
-    cdef uintptr_t p_flags = f8.data_ptr(), p_index = index.data_ptr(), p_count = count.data_ptr(), p_ws = ws.data_ptr()
+    cdef uintptr_t stream = 0, p_flags, p_index
+    cdef uint64_t n, k = 0
     cdef int retval
+    if _is_device_tensor(flags):
+        torch = _lib._torch
+        f8 = flags.contiguous().view(torch.uint8) if flags.dtype in (torch.bool, torch.uint8, torch.int8) \
+            else (flags != 0).to(torch.uint8)
+        n = int(f8.numel())
+        index = torch.empty((max(n, 1),), dtype=torch.int32, device=f8.device)
+        stream = torch.cuda.current_stream(f8.device).cuda_stream
+        p_flags, p_index = f8.data_ptr(), index.data_ptr()
+        keep = (f8, index)
+    else:
+        ptr, nbytes = _device_memory(flags, "flags")
+        iface = flags.__cuda_array_interface__
+        if numpy.dtype(iface['typestr']).itemsize != 1:
+            raise ValueError("flags must have one-byte elements")
+        n = nbytes
+        index = DeviceBuffer((max(n, 1),), numpy.int32, getattr(flags, 'device', -1) if isinstance(flags, DeviceBuffer) else -1)
+        p_flags, p_index = ptr, index.ptr
+        keep = (flags, index)
     with nogil:
-        retval = C.pgsd_select_rows(<const uint8_t*>p_flags, n, <uint32_t*>p_index, <uint64_t*>p_count, <void*>p_ws,
-                                    <void*>stream)
+        retval = C.pgsd_select_rows(<const uint8_t*>p_flags, n, <uint32_t*>p_index, &k, <void*>stream)
     _raise_on_error(retval, "select_rows")
-    k = int(count.item())          # synchronises the stream
-    return index[:k], k
+    if isinstance(index, DeviceBuffer):
+        return index.view(shape=(int(k),)), int(k)
+    return index[:int(k)], int(k)
 
 
 def open(name, mode, application=None, schema=None, schema_version=None, comm=None):
@@ -557,7 +742,13 @@ cdef class PGSDFile:
     def local_reads(self):
         """bool: reads on a writable file take no part in a collective flush (``pgsd_set_local_reads``): for rows the
         caller knows to be in the file -- this rank's own rows of a sealed frame, or a file opened after they were
-        written.  Default False: a read flushes first, collectively, like the reference's (pgsd.c:2436-2537)."""
+        written.  Default False: a read flushes first, collectively, like the reference's (pgsd.c:2436-2537).
+
+        With several ranks the LOOKUP in front of a read (:meth:`chunk_exists`, :meth:`read_chunk`,
+        :meth:`find_matching_chunk_names`) is local too while this is on: it sees what the last collective flush
+        committed.  A frame that held buffered small chunks only is not flushed by :meth:`end_frame`
+        (pgsd.c:1941-1950), so its chunks are reported missing until the next :meth:`flush`; the library then leaves
+        a note in ``pgsd_last_error_string()``.  On ONE rank the flush concerns nobody else and runs as ever."""
         return bool(self._local_reads)
 
     @local_reads.setter
@@ -604,8 +795,10 @@ cdef class PGSDFile:
     @property
     def collective_count(self):
         """int: allgathers / barriers this handle has issued on its communicator."""
+        cdef C.pgsd_exchange_stats st
         self._check_open()
-        return int(C.pgsd_get_collective_count(&self._handle))
+        _raise_on_error(C.pgsd_get_exchange_stats(&self._handle, &st, 0), self._name)
+        return int(st.collectives)
 
     def exchange_stats(self, reset=False):
         """dict ``count``, ``total_us``, ``max_us``, ``min_us``: the allgathers this handle issued and their wall
@@ -829,8 +1022,20 @@ cdef class PGSDFile:
         finally:
             free(reqs)
         _raise_on_error(retval, self._name, err)
-        # (ticket, rows, packed bytes of every chunk, the GPU the sources -- and with them the staging -- live on)
-        return (int(ticket), int(N), tuple(sizes), _device_index_of(fields[0][1]))
+        # (ticket, rows, packed bytes of every chunk, the GPU the pipeline -- and with it the staging -- lives on: the
+        # handle's own answer, whatever kind of array the sources are and whatever a tensor library's "current device" is)
+        return (int(ticket), int(N), tuple(sizes), self.pipeline_device())
+
+    def pipeline_device(self):
+        """int: the HIP device this file's pipeline runs on (created on the device given to :meth:`configure_device`,
+        else on the device that is current at the first device call)."""
+        cdef int dev
+        self._check_open()
+        with nogil:
+            dev = C.pgsd_device_of(&self._handle)
+        if dev < 0:
+            _raise_on_error(dev, self._name)
+        return dev
 
     def write_staged(self, ticket, first, count, offset=None, rank=0):
         """Write chunks ``[first, first + count)`` of a :meth:`stage_chunks` ticket at this point of the frame
@@ -848,8 +1053,9 @@ cdef class PGSDFile:
 
     def compare_staged(self, ticket, first, refs):
         """Do the packed rows of staged chunks ``first, first + 1, ...`` of a :meth:`stage_chunks` ticket equal
-        ``refs[i]`` -- torch GPU tensors holding the same rows of another frame as the chunk stores them
-        (:meth:`read_chunk_device`, :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  A reference SHORTER
+        ``refs[i]`` -- dense arrays in GPU memory (:class:`DeviceBuffer`, torch GPU tensors, ``__cuda_array_interface__``
+        objects) holding the same rows of another frame as the chunk stores them (:meth:`read_chunk_device`,
+        :meth:`copy_staged`), or ``None`` (not compared: ``False``)?  A reference SHORTER
         than the chunk repeats (rows of a default value: at least 4096 bytes, a multiple of 16 bytes and of whole
         rows).  One kernel behind the pack, one stream wait (``pgsd_compare_staged_chunks``).  Equality is
         ``numpy.array_equal``'s: integer chunks by their bytes, float chunks by value (a NaN equals nothing, +0.0 equals
@@ -877,17 +1083,15 @@ cdef class PGSDFile:
                 r = refs[i]
                 if r is None:
                     continue
-                if not _is_device_tensor(r) or not r.is_contiguous():
-                    raise ValueError("a reference must be a contiguous torch GPU tensor (or None)")
+                addr, have = _device_memory(r, "a reference")
                 if first + i >= len(ticket[2]):
                     raise ValueError("the ticket has no chunk %d" % (first + i))
-                have = r.numel() * r.element_size()
                 if have > ticket[2][first + i]:
                     # the kernel reads as many bytes of the reference as the packed chunk has: never fewer at hand
                     # (a shorter one repeats; the library checks its shape)
                     raise ValueError("reference %d holds more than the %d bytes of the packed chunk" % (i, ticket[2][first + i]))
                 sizes[i] = have
-                p = r.data_ptr()
+                p = addr
                 # an empty tensor has no address: any non-null one says "there is a reference" (no byte is read)
                 ptrs[i] = <const void*>p if p != 0 else <const void*>ptrs
             with nogil:
@@ -901,18 +1105,11 @@ cdef class PGSDFile:
             free(eq)
 
     def copy_staged(self, ticket, first, sizes):
-        """Keep the packed bytes of staged chunks ``first, first + 1, ...`` of a ticket: returns one ``torch.uint8`` GPU
-        tensor of ``sizes[i]`` bytes per chunk (``None`` where ``sizes[i]`` is ``None``), filled asynchronously behind the
-        pack (``pgsd_copy_staged_chunks``) -- references for :meth:`compare_staged` in later frames."""
+        """Keep the packed bytes of staged chunks ``first, first + 1, ...`` of a ticket: returns one :class:`DeviceBuffer`
+        of ``sizes[i]`` bytes per chunk (``None`` where ``sizes[i]`` is ``None``), filled asynchronously behind the
+        pack (``pgsd_copy_staged_chunks``) -- references for :meth:`compare_staged` in later frames.  The buffers are
+        the library's own, on the GPU the staging lives on (which need not be a tensor library's current device)."""
         self._check_open()
-        import torch
-        # The destinations come from torch's caching allocator: a recycled block may still be in use by work queued
-        # on torch's stream, so the copies (on the pack stream) are ordered behind that stream like every other
-        # device call that touches caller memory (ADVICE r3) -- and they live on the GPU the staging lives on, which
-        # need not be torch's current device.
-        if not self._explicit_stream:
-            self._sync_source_stream()
-        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else torch.cuda.current_device()
         cdef Py_ssize_t n = len(sizes), i
         if n == 0:
             return []
@@ -920,6 +1117,7 @@ cdef class PGSDFile:
             if sizes[i] is not None and (first + i >= len(ticket[2]) or int(sizes[i]) != ticket[2][first + i]):
                 raise ValueError("chunk %d of the ticket has %d packed bytes" % (first + i, ticket[2][first + i]
                                                                                  if first + i < len(ticket[2]) else -1))
+        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else self.pipeline_device()
         cdef uint64_t c_ticket = ticket[0]
         cdef uint32_t c_first = first, c_count = n
         cdef void** ptrs = <void**>calloc(n, sizeof(void*))
@@ -933,9 +1131,9 @@ cdef class PGSDFile:
                 if sizes[i] is None:
                     out.append(None)
                     continue
-                t = torch.empty(int(sizes[i]), dtype=torch.uint8, device=torch.device('cuda', device))
+                t = DeviceBuffer((int(sizes[i]),), numpy.uint8, device)
                 out.append(t)
-                p = t.data_ptr()
+                p = t.ptr
                 ptrs[i] = <void*>p
             with nogil:
                 retval = C.pgsd_copy_staged_chunks(&self._handle, c_ticket, c_first, c_count, ptrs)
@@ -1083,7 +1281,7 @@ cdef class PGSDFile:
             the destination tensor.
         """
         self._check_open()
-        import torch
+        torch = _lib._torch
         cdef const C.pgsd_index_entry* e = self._find(frame, name)
         if e == NULL:
             raise KeyError("frame " + str(frame) + " / chunk " + name + " not found in: " + self._name)
@@ -1097,33 +1295,65 @@ cdef class PGSDFile:
             raise ValueError("row range outside the chunk: " + name)
         np_dt = _PGSD_TO_NP[etype]
         if out is None:
-            tdt = getattr(torch, np_dt.name)
-            out = torch.empty((N, eM) if eM > 1 else (N,), dtype=tdt, device='cuda')
-        if not _is_device_tensor(out):
-            raise ValueError("out must be a torch GPU tensor")
-        t2 = out.unsqueeze(1) if out.dim() == 1 else out
-        if t2.dim() != 2 or (t2.shape[1] > 1 and t2.stride(1) != 1):
-            raise ValueError("out must be 1-D or row-major 2-D")
-        stride = int(t2.stride(0)) if t2.shape[0] > 1 else int(t2.shape[1])
+            # on the GPU the pipeline runs on (not a tensor library's "current device"); a torch tensor where torch
+            # is importable, the library's own memory otherwise
+            device = self.pipeline_device()
+            if torch is not None:
+                out = torch.empty((N, eM) if eM > 1 else (N,), dtype=getattr(torch, np_dt.name),
+                                  device=torch.device('cuda', device))
+            else:
+                out = DeviceBuffer((N, eM) if eM > 1 else (N,), np_dt, device)
+        cdef uintptr_t p_dst, p_order = 0
+        if _is_device_tensor(out):
+            t2 = out.unsqueeze(1) if out.dim() == 1 else out
+            if t2.dim() != 2 or (t2.shape[1] > 1 and t2.stride(1) != 1):
+                raise ValueError("out must be 1-D or row-major 2-D")
+            rows, width = int(t2.shape[0]), int(t2.shape[1])
+            stride = int(t2.stride(0)) if rows > 1 else width
+            out_dtype = t2.dtype
+            p_dst = t2.data_ptr()
+        else:
+            iface = getattr(out, '__cuda_array_interface__', None) if not hasattr(out, 'data_ptr') or isinstance(out, DeviceBuffer) else None
+            if not isinstance(iface, dict):
+                raise ValueError("out must live in GPU memory (torch GPU tensor, DeviceBuffer or __cuda_array_interface__)")
+            out_dtype = numpy.dtype(iface['typestr'])
+            shp = tuple(int(v) for v in iface['shape'])
+            if len(shp) == 1:
+                shp = (shp[0], 1)
+            if len(shp) != 2:
+                raise ValueError("out must be 1-D or row-major 2-D")
+            rows, width = shp
+            st = iface.get('strides')
+            if st is not None and len(iface['shape']) == 2:
+                if (width > 1 and int(st[1]) != out_dtype.itemsize) or int(st[0]) % out_dtype.itemsize != 0:
+                    raise ValueError("out must be 1-D or row-major 2-D")
+                stride = int(st[0]) // out_dtype.itemsize if rows > 1 else width
+            elif st is not None:
+                if int(st[0]) % out_dtype.itemsize != 0:
+                    raise ValueError("out must be 1-D or row-major 2-D")
+                stride = int(st[0]) // out_dtype.itemsize if rows > 1 else 1
+            else:
+                stride = width
+            p_dst = int(iface['data'][0]) if rows * width > 0 else 0
         c0 = 0 if columns is None else int(columns[0])
         if columns is not None and int(columns[1]) - c0 != eM:
             raise ValueError("columns must span the chunk's %d columns" % eM)
-        if c0 + eM > max(stride, int(t2.shape[1])):
+        if c0 + eM > max(stride, width):
             raise ValueError("chunk does not fit the destination rows")
-        if order is None and int(t2.shape[0]) < N:
+        if order is None and rows < N:
             raise ValueError("destination has fewer rows than requested")
+        if order is not None:
+            p_order = _device_memory(order, "order")[0]
         cdef C.pgsd_field_dst dst
         memset(&dst, 0, sizeof(dst))
-        cdef uintptr_t p_dst = t2.data_ptr()
-        cdef uintptr_t p_order = order.data_ptr() if order is not None else 0
         dst.dst = <void*>p_dst
         dst.order = <const uint32_t*>p_order
-        dst.dst_type = _pgsd_type(t2.dtype, name)
+        dst.dst_type = _pgsd_type(out_dtype, name)
         dst.dst_stride = stride
         dst.dst_col0 = c0
         dst.bitcast = 1 if bitcast else 0
         if fill is not None:
-            np_out = numpy.dtype(str(t2.dtype)[6:])
+            np_out = numpy.dtype(str(out_dtype)[6:]) if str(out_dtype).startswith('torch.') else numpy.dtype(out_dtype)
             dst.fill_rest = 1
             dst.fill_bits = int(numpy.array([fill], dtype=np_out).view(numpy.dtype('u%d' % np_out.itemsize))[0])
         self._keepalive.append((out, order))

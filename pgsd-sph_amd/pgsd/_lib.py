@@ -117,7 +117,7 @@ class DeviceStats(ctypes.Structure):
 
 
 class ExchangeStats(ctypes.Structure):
-    _fields_ = [("count", c_u64), ("total_us", ctypes.c_double), ("max_us", ctypes.c_double),
+    _fields_ = [("collectives", c_u64), ("count", c_u64), ("total_us", ctypes.c_double), ("max_us", ctypes.c_double),
                 ("min_us", ctypes.c_double)]
 
 
@@ -141,7 +141,10 @@ def _sig(name, restype, *argtypes):
     return fn
 
 
-# every symbol include/pgsd.h declares (tests/test_abi.py checks the list against the header)
+ABI_VERSION = 5     # PGSD_ABI_VERSION of the include/pgsd.h these signatures were written against
+
+# every symbol include/pgsd.h declares (tests/test_abi.py checks the list against the header); the entry points of
+# csrc/pgsd_private.h (bare kernels, queue plumbing, housekeeping: tests, tools, bench legs) follow at the end
 _sig("pgsd_make_version", c_u32, ctypes.c_uint, ctypes.c_uint)
 _sig("pgsd_create_and_open", c_i32, HP, c_cp, c_cp, c_cp, c_u32, c_i32, c_i32)
 _sig("pgsd_open", c_i32, HP, c_cp, c_i32)
@@ -165,11 +168,8 @@ _sig("pgsd_set_index_entries_to_buffer", c_i32, HP, c_u64)
 _sig("pgsd_bcast_index_entry", None, ctypes.POINTER(IndexEntry))
 _sig("pgsd_last_error_string", c_cp)
 _sig("pgsd_comm_set_default", c_i32, ctypes.POINTER(Comm))
-_sig("pgsd_comm_init_self", c_i32)
-_sig("pgsd_comm_init_shm", c_i32, c_cp, c_i32, c_i32)
 _sig("pgsd_comm_init_from_env", c_i32)
 _sig("pgsd_comm_rccl_unique_id", c_i32, c_vp)
-_sig("pgsd_comm_init_rccl", c_i32, c_vp, c_i32, c_i32, c_i32)
 _sig("pgsd_comm_rccl_available", c_i32, c_i32)
 _sig("pgsd_device_release_parked", c_i32)
 _sig("pgsd_comm_finalize", c_i32)
@@ -202,14 +202,25 @@ _sig("pgsd_frame_exchange", c_i32, HP)
 _sig("pgsd_set_deferred_rows", c_i32, HP, c_i32)
 _sig("pgsd_set_local_reads", c_i32, HP, c_i32)
 _sig("pgsd_set_partition", c_i32, HP, ctypes.POINTER(c_u64), c_u32)
-_sig("pgsd_get_collective_count", c_u64, HP)
 _sig("pgsd_get_exchange_stats", c_i32, HP, ctypes.POINTER(ExchangeStats), c_i32)
 _sig("pgsd_unpack_fields", c_i32, c_u32, ctypes.POINTER(UnpackJob), c_u64, c_vp)
 _sig("pgsd_read_chunk_device", c_i32, HP, ctypes.POINTER(IndexEntry), c_u64, c_u64, ctypes.POINTER(FieldDst))
 _sig("pgsd_device_wait_read", c_i32, HP)
-_sig("pgsd_select_workspace_bytes", ctypes.c_size_t, c_u64)
-_sig("pgsd_select_rows", c_i32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp)
+_sig("pgsd_select_rows", c_i32, c_vp, c_u64, c_vp, ctypes.POINTER(c_u64), c_vp)
+_sig("pgsd_device_alloc", c_vp, c_i32, ctypes.c_size_t, c_vp, ctypes.c_size_t)
+_sig("pgsd_device_free", c_i32, c_i32, c_vp)
+_sig("pgsd_abi_version", c_u32)
 _sig("pgsd_device_available", c_i32)
+
+
+# csrc/pgsd_private.h
+_sig("pgsd_reload_tuning", None)
+_sig("pgsd_device_of", c_i32, HP)
+_sig("pgsd_device_copy", c_i32, c_i32, c_vp, c_vp, ctypes.c_size_t)
+
+if lib.pgsd_abi_version() != ABI_VERSION:
+    raise ImportError("libpgsd_amd.so at %s has ABI version %d, these bindings were written against %d: rebuild "
+                      "(`make -C pgsd-sph_amd/csrc`)" % (LIB_PATH, lib.pgsd_abi_version(), ABI_VERSION))
 
 
 def last_error():

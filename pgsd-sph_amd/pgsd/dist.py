@@ -29,15 +29,36 @@ def _retire():
 
 
 def init_self():
-    lib.pgsd_comm_init_self()
+    lib.pgsd_comm_finalize()        # back to the single-rank communicator (the state after library load)
     _retire()
 
 
-def init_shm(name, rank, size):
-    """Ranks of one node meeting in /dev/shm/<name> (no torch needed)."""
-    rc = lib.pgsd_comm_init_shm(name.encode(), rank, size)
+def _install(comm, what):
+    """Make a communicator created by pgsd_comm_create_* the process default (the default takes it over)."""
+    rc = lib.pgsd_comm_set_default(ctypes.byref(comm))
     if rc != 0:
-        raise RuntimeError("pgsd_comm_init_shm failed: " + _lib.last_error())
+        lib.pgsd_comm_release(ctypes.byref(comm))
+        raise RuntimeError("pgsd_comm_set_default(%s) failed: %s" % (what, _lib.last_error()))
+    return rc
+
+
+def init_shm(name, rank, size):
+    """Ranks of one node meeting in /dev/shm/<name> (no torch needed), installed as the process default."""
+    comm = _lib.Comm()
+    rc = lib.pgsd_comm_create_shm(name.encode(), int(rank), int(size), ctypes.byref(comm))
+    if rc != 0:
+        raise RuntimeError("pgsd_comm_create_shm failed: " + _lib.last_error())
+    _install(comm, "shm")
+
+
+def init_rccl(unique_id, rank, size, device):
+    """An RCCL communicator (pgsd_comm_create_rccl) installed as the process default; returns the C status (0 = ok,
+    the reason in ``pgsd._lib.last_error()``)."""
+    comm = _lib.Comm()
+    rc = lib.pgsd_comm_create_rccl(bytes(unique_id), int(rank), int(size), int(device), ctypes.byref(comm))
+    if rc != 0:
+        return rc
+    return lib.pgsd_comm_set_default(ctypes.byref(comm))
 
 
 def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=False):
@@ -80,7 +101,7 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
             raise RuntimeError("the RCCL back end is not available on at least one rank: " + (err or "(another rank)"))
         dist.broadcast(uid, src=0, group=group)
         host = bytes(uid.cpu().tolist())
-        rc = lib.pgsd_comm_init_rccl(host, rank, size, int(device))
+        rc = init_rccl(host, rank, size, int(device))
         err = _lib.last_error() if rc != 0 else ""
         if rc == 0:
             # one real exchange before the communicator is trusted with file offsets
@@ -95,7 +116,7 @@ def init_from_torch(group=None, device=None, prefer_rccl=True, _single_rank_too=
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 0:
             lib.pgsd_comm_finalize()
-            raise RuntimeError("pgsd_comm_init_rccl failed on at least one rank: " + (err or "(another rank)"))
+            raise RuntimeError("pgsd_comm_create_rccl failed on at least one rank: " + (err or "(another rank)"))
         return "rccl" if not chosen else "rccl[%s]" % os.path.basename(chosen)
 
     on_gpu = backend == "nccl"

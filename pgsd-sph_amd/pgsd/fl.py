@@ -15,7 +15,7 @@ except ImportError as e:  # pragma: no cover - a checkout that was never built
     raise ImportError("pgsd/_fl (the Cython file layer) is not built: run `make -C pgsd-sph_amd/csrc` "
                       "(or python -c 'import __graft_entry__ as g; g.build()'): %s" % e)
 
-from ._fl import DeviceField, PGSDFile, open, select_rows, logger  # noqa: E402,F401
+from ._fl import DeviceBuffer, DeviceField, PGSDFile, open, select_rows, logger  # noqa: E402,F401
 from ._fl import _is_device_tensor, _is_device_array, _pgsd_type, _NP_TO_PGSD, _PGSD_TO_NP  # noqa: E402,F401
 
-__all__ = ["open", "PGSDFile", "DeviceField", "select_rows"]
+__all__ = ["open", "PGSDFile", "DeviceField", "DeviceBuffer", "select_rows"]

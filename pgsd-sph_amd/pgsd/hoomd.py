@@ -397,11 +397,9 @@ class HOOMDTrajectory(object):
             with this rank's rows of frame 0 where frame 0 holds the chunk, with the default value where it does
             not -- and the file is the one host arrays of the same values give, for every input (NaNs, signed zeros,
             arrays that return to frame 0's values, default-valued arrays); the price is one frame's worth of HBM for
-            the rows of frame 0 and one comparison launch per frame.  ``'once'`` (``'bytes-once'`` is accepted for it:
-            round 3's default, whose comparison was of bytes; equality is numpy's in every mode now): an array that differed once is
-            written from then on without a comparison (a moving array costs nothing after the first frame; an array
-            that returns to frame 0's values is written where the host path would elide it).  False: GPU-resident
-            arrays are always written.
+            the rows of frame 0 and one comparison launch per frame.  False: GPU-resident arrays are always written.
+            (Round 3's ``'once'`` shortcut -- stop comparing an array once it differed -- was removed in round 5: it
+            wrote arrays that return to frame 0's values where the host path elides them.)
 
     Per-particle attributes of a `Frame` may be numpy arrays, torch GPU tensors or `pgsd.fl.DeviceField` views of
     GPU memory (a column range of a ``Scalar4`` array, a converted or bit-cast element type); `append` writes the
@@ -421,7 +419,6 @@ class HOOMDTrajectory(object):
         self.device_elision = True
         self._dev_ref = {}             # chunk -> GPU tensor: this rank's rows of frame 0 as the chunk stores them
         self._dev_ref_part = None      # the partition (every rank's row count) those rows belong to
-        self._dev_dynamic = set()      # device_elision='once': GPU-resident chunks seen to differ, not compared any more
         self._default_ref = {}         # (chunk, device) -> GPU tensor: rows of the default value as the chunk stores them
         self._dev_off = False          # the partition changed: frame 0's rows are other particles' from now on
         self._host_ref = {}            # several ranks: chunk -> this rank's rows of frame 0 (host arrays are compared too)
@@ -660,12 +657,6 @@ class HOOMDTrajectory(object):
             self._dev_ref.clear()
             self._host_ref.clear()
             return
-        if self.device_elision in ('once', 'bytes-once'):
-            for k in plan.compared:
-                at, chunk, _ = plan.dev[k]
-                if plan.entries[at][2]:
-                    self._dev_dynamic.add(chunk)        # differs (on some rank): a moving array, not compared again
-                    self._dev_ref.pop(chunk, None)
 
     # -- step 3: the chunks, in the reference's order
     def _write_frame(self, plan, frame, rank, size, wait):
@@ -816,15 +807,15 @@ class HOOMDTrajectory(object):
         key = (chunk, device)
         ref = self._default_ref.get(key)
         if ref is None:
-            import torch
             name = chunk.split('/', 1)[1]
             default = ParticleData._default_value.get(name, ParticleData._extra_default_value.get(name))
-            rows = numpy.empty((4096, int(field.M)), dtype=field.out_dtype)
-            rows[...] = default
-            ref = torch.from_numpy(rows.view(numpy.uint8).reshape(-1)).to(torch.device('cuda', device))
+            row = numpy.empty((1, int(field.M)), dtype=field.out_dtype)
+            row[...] = default
+            # 4096 rows of the default value in the library's own device memory: ONE row repeated by the allocation
+            ref = fl.DeviceBuffer((4096 * row.nbytes,), numpy.uint8, device, pattern=row)
             self._default_ref[key] = ref
         want = int(field.N) * int(field.M) * field.out_dtype.itemsize
-        return ref if want >= ref.numel() else ref[:want]
+        return ref if want >= ref.nbytes else ref.view(shape=(want,))
 
     def _device_votes(self, plan, rank):
         """The elision rule of hoomd.py:654-694 for GPU-resident per-particle arrays, decided on the GPU exactly as
@@ -836,8 +827,9 @@ class HOOMDTrajectory(object):
         All of the frame's GPU-resident arrays are packed by ONE launch into staging (`stage_chunks`) and compared by
         one more (`compare_staged`: one stream wait).  Frame 0's rows come from the staging of frame 0 itself when
         this trajectory wrote it (`copy_staged` in `_write_frame`: a device-to-device copy), from the file otherwise
-        (`read_chunk_device`, once per array).  ``device_elision = 'once'``: an array that differed once is written
-        from then on without a comparison; ``False``: no comparisons, every array that is set is written."""
+        (`read_chunk_device`, once per array).  ``device_elision = False``: no comparisons, every array that is set
+        is written.  Everything the comparison keeps in HBM is the library's own memory (`pgsd.fl.DeviceBuffer`) on
+        the GPU the file's pipeline runs on: no tensor library is involved, whatever kind of array the sources are."""
         f = self.file
         dev = plan.dev
         if not dev or not self.device_elision or not hasattr(f, 'compare_staged'):
@@ -848,8 +840,6 @@ class HOOMDTrajectory(object):
         kinds = [None] * len(dev)                   # 'rows': against frame 0's rows; 'default': against the default
         device = None
         for k, (_, chunk, field) in enumerate(dev):
-            if chunk in self._dev_dynamic:
-                continue
             if chunk in frame0:
                 if part0 is not None and not self._dev_off:
                     kinds[k] = 'rows'
@@ -858,10 +848,7 @@ class HOOMDTrajectory(object):
         if not any(kinds):
             return
         ticket = f.stage_chunks([(chunk, field) for _, chunk, field in dev])
-        device = ticket[3] if len(ticket) > 3 and ticket[3] is not None else None
-        if device is None:              # fields built from bare pointers: the pipeline runs on the current device
-            import torch
-            device = torch.cuda.current_device()
+        device = ticket[3]              # the GPU the file's pipeline runs on (the handle's own answer)
         row0 = sum(part0[:rank]) if part0 is not None else 0
         for k, (_, chunk, field) in enumerate(dev):
             if kinds[k] == 'default':
@@ -1106,9 +1093,11 @@ class HOOMDTrajectory(object):
                 read, a third of a 1 024-particle frame's 90 us; False leaves them ``None``.
 
         Returns:
-            `Frame` whose ``particles.N`` is this rank's count, ``particles.N_global`` the total.
+            `Frame` whose ``particles.N`` is this rank's count, ``particles.N_global`` the total.  The per-particle
+            arrays are torch GPU tensors where torch is importable, `pgsd.fl.DeviceBuffer` objects (the library's own
+            device memory, ``__cuda_array_interface__``) otherwise -- on the GPU the file's pipeline runs on.
         """
-        import torch
+        torch = fl._lib._torch          # None: no tensor library in this process
         if idx < 0:
             idx += len(self)
         if idx >= len(self) or idx < 0:
@@ -1187,32 +1176,48 @@ class HOOMDTrajectory(object):
                 # (one clone of a 40-word template per frame, not one host->device copy per field): a write
                 # through a view changes this frame's view only, never a later frame's default
                 if default_rows is None:
-                    default_rows = self._default_rows_template().clone()
-                off, words, tdt = self._default_rows_layout[name]
-                base = typed.get(tdt)
-                if base is None:
-                    base = typed[tdt] = default_rows.view(tdt)      # one re-typed view of the copy per element type
-                # one strided view per attribute: n rows that are all the same `words` elements (stride 0)
-                setattr(snap.particles, name, base.as_strided((n, M) if M > 1 else (n,), (0, 1) if M > 1 else (0,), off))
+                    default_rows = self._default_rows_template(f.pipeline_device()).clone()
+                off, words, ndt = self._default_rows_layout[name]
+                if torch is None:
+                    # one strided view per attribute: n rows that are all the same `words` elements (stride 0)
+                    view = default_rows.view(dtype=ndt, shape=(n, M) if M > 1 else (n,),
+                                             strides=(0, ndt.itemsize) if M > 1 else (0,), offset_bytes=4 * off)
+                else:
+                    tdt = getattr(torch, ndt.name)
+                    base = typed.get(tdt)
+                    if base is None:
+                        base = typed[tdt] = default_rows.view(tdt)  # one re-typed view of the copy per element type
+                    view = base.as_strided((n, M) if M > 1 else (n,), (0, 1) if M > 1 else (0,), off)
+                setattr(snap.particles, name, view)
         if scalar4 and n >= 0:
             # HOOMD's Scalar4 arrays, every row stored WHOLE by the unpack launch: the columns a missing chunk
             # would have fed come from the `fill` of the chunk that is there (type id 0 as bits, mass 1.0,
             # position / velocity 0) -- no memset of the arrays, no 12-byte stores at a 16-byte stride
-            pos4 = torch.empty((n, 4), dtype=torch.float32, device='cuda')
-            vel4 = torch.empty((n, 4), dtype=torch.float32, device='cuda')
-            for arr, xyz, w, w_bitcast, w_default in ((pos4, 'particles/position', 'particles/typeid', True, 0.0),
-                                                      (vel4, 'particles/velocity', 'particles/mass', False, 1.0)):
+            device = f.pipeline_device()
+            arrays = []
+            for xyz, w, w_bitcast, w_default in (('particles/position', 'particles/typeid', True, 0.0),
+                                                 ('particles/velocity', 'particles/mass', False, 1.0)):
                 f_xyz, f_w = frame_of(xyz), frame_of(w)
+                if f_xyz is None and f_w is None:
+                    # neither chunk anywhere: rows of (0, 0, 0, default w)
+                    row = numpy.array([0.0, 0.0, 0.0, w_default], dtype=numpy.float32)
+                    if torch is None:
+                        arr = fl.DeviceBuffer((n, 4), numpy.float32, device, pattern=row)
+                    else:
+                        arr = torch.zeros((n, 4), dtype=torch.float32, device=torch.device('cuda', device))
+                        arr[:, 3] = w_default
+                elif torch is None:
+                    arr = fl.DeviceBuffer((n, 4), numpy.float32, device)
+                else:
+                    arr = torch.empty((n, 4), dtype=torch.float32, device=torch.device('cuda', device))
+                arrays.append(arr)
                 if f_xyz is not None:
                     f.read_chunk_device(f_xyz, xyz, out=arr, N=n, offset=row0, columns=(0, 3), wait=False,
                                         fill=w_default if f_w is None else None)
                 if f_w is not None:
                     f.read_chunk_device(f_w, w, out=arr, N=n, offset=row0, columns=(3, 4), bitcast=w_bitcast, wait=False,
                                         fill=0.0 if f_xyz is None else None)
-                if f_xyz is None and f_w is None:
-                    arr.zero_()
-                    arr[:, 3] = w_default
-            snap.particles.pos4, snap.particles.vel4 = pos4, vel4
+            snap.particles.pos4, snap.particles.vel4 = arrays
         f.wait_read()
         for name, chunk in fresh:
             cache[chunk] = getattr(snap.particles, name).clone()
@@ -1225,23 +1230,26 @@ class HOOMDTrajectory(object):
                 snap.state[state[6:]] = f.read_chunk(idx, state)
         return snap
 
-    def _default_rows_template(self):
-        """All default rows of the SPH schema as ONE int32 device tensor (every element type of the schema is four
-        bytes wide), built once per trajectory and device; `_default_rows_layout[name]` = (first word, words, torch
-        dtype).  `read_frame_device` clones it per read and hands out views of the clone."""
-        import torch
-        dev = torch.cuda.current_device()
+    def _default_rows_template(self, device):
+        """All default rows of the SPH schema as ONE int32 device array (every element type of the schema is four
+        bytes wide), built once per trajectory and device; `_default_rows_layout[name]` = (first word, words, numpy
+        dtype).  `read_frame_device` clones it per read and hands out views of the clone.  A torch tensor where torch
+        is importable, the library's own device memory otherwise."""
         cached = getattr(self, '_default_rows_cache', None)
-        if cached is not None and cached[0] == dev:
+        if cached is not None and cached[0] == device:
             return cached[1]
         words, layout = [], {}
         for name, (dt, M) in _PARTICLE_SPEC.items():
             row = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(ParticleData._default_value[name], dtype=dt), (M,)))
-            layout[name] = (len(words), M, getattr(torch, numpy.dtype(dt).name))
+            layout[name] = (len(words), M, numpy.dtype(dt))
             words += row.view(numpy.int32).tolist()
-        template = torch.tensor(words, dtype=torch.int32, device='cuda')
+        torch = fl._lib._torch
+        if torch is None:
+            template = fl.DeviceBuffer((len(words),), numpy.int32, device, pattern=numpy.array(words, dtype=numpy.int32))
+        else:
+            template = torch.tensor(words, dtype=torch.int32, device=torch.device('cuda', device))
         self._default_rows_layout = layout
-        self._default_rows_cache = (dev, template)
+        self._default_rows_cache = (device, template)
         return template
 
     def _frame0_small(self, chunk):

@@ -108,12 +108,10 @@ cdef extern from "pgsd.h" nogil:
 
     # ---- frame exchange, communicators
     int pgsd_set_frame_exchange(pgsd_handle* handle, int batched)
-    int pgsd_set_deferred_rows(pgsd_handle* handle, int on)
     int pgsd_set_local_reads(pgsd_handle* handle, int on)
     int pgsd_set_partition(pgsd_handle* handle, const uint64_t* rows, uint32_t n_ranks)
-    int pgsd_frame_exchange(pgsd_handle* handle)
-    uint64_t pgsd_get_collective_count(pgsd_handle* handle)
     cdef struct pgsd_exchange_stats:
+        uint64_t collectives
         uint64_t count
         double total_us
         double max_us
@@ -189,9 +187,19 @@ cdef extern from "pgsd.h" nogil:
     int pgsd_device_configure(pgsd_handle* handle, const pgsd_device_config* cfg)
     int pgsd_device_set_source_stream(pgsd_handle* handle, void* stream)
     int pgsd_device_get_stats(pgsd_handle* handle, pgsd_device_stats* out, int reset)
-    size_t pgsd_select_workspace_bytes(uint64_t N)
-    int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count, void* workspace,
-                         void* stream)
+    int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count, void* stream)
+    void* pgsd_device_alloc(int device, size_t bytes, const void* pattern, size_t pattern_bytes)
+    int pgsd_device_free(int device, void* ptr)
+    uint32_t PGSD_ABI_VERSION
+    uint32_t pgsd_abi_version()
     int pgsd_read_chunk_device(pgsd_handle* handle, const pgsd_index_entry* chunk, uint64_t N, uint64_t row_offset,
                                const pgsd_field_dst* dst)
     int pgsd_device_wait_read(pgsd_handle* handle)
+
+
+# entry points that are not part of the public C ABI (csrc/pgsd_private.h): queue plumbing and binding helpers
+cdef extern from "pgsd_private.h" nogil:
+    int pgsd_set_deferred_rows(pgsd_handle* handle, int on)
+    int pgsd_frame_exchange(pgsd_handle* handle)
+    int pgsd_device_of(pgsd_handle* handle)
+    int pgsd_device_copy(int device, void* dst, const void* src, size_t bytes)

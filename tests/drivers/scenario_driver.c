@@ -79,6 +79,9 @@
  *   names <prefix>                 (prints matching chunk names on rank 0)
  */
 #include "pgsd.h"
+#if !defined(PGSD_DRIVER_REF)
+#include "pgsd_private.h" /* queue plumbing of the product: pgsd_set_deferred_rows, pgsd_frame_exchange */
+#endif
 
 #include <inttypes.h>
 #include <stdio.h>

@@ -6,8 +6,10 @@ import uuid
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pgsd-sph_amd", "csrc")
 LIB = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
-DRIVER = os.path.join(CSRC, "build", "scenario_driver")
-DEVICE_DRIVER = os.path.join(CSRC, "build", "scenario_driver_device")      # rows of every chunk write from HBM
+TESTS = os.path.join(ROOT, "tests")
+TBUILD = os.path.join(TESTS, "build")           # tests/Makefile: drivers, the stand-in librccl, sanitizer builds
+DRIVER = os.path.join(TBUILD, "scenario_driver")
+DEVICE_DRIVER = os.path.join(TBUILD, "scenario_driver_device")      # rows of every chunk write from HBM
 
 _built = False
 
@@ -27,10 +29,11 @@ def locked_make(args, check=True, **kw):
 
 
 def build():
-    """make -C pgsd-sph_amd/csrc (no-op when up to date)."""
+    """make -C pgsd-sph_amd/csrc, then make -C tests (no-ops when up to date)."""
     global _built
     if not _built:
         locked_make(["-C", CSRC, "-j8"], stdout=subprocess.DEVNULL)
+        locked_make(["-C", TESTS, "-j8"], stdout=subprocess.DEVNULL)
         _built = True
     return LIB
 

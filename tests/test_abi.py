@@ -6,11 +6,14 @@ import re
 import product
 
 
-def declared_symbols():
-    hdr = open(os.path.join(product.ROOT, "include", "pgsd.h")).read()
+def declared_symbols(path=None):
+    hdr = open(path or os.path.join(product.ROOT, "include", "pgsd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(pgsd_[a-z0-9_]+)\s*\(", hdr))
     return sorted(names)
+
+
+PRIVATE_HEADER = os.path.join(product.CSRC, "pgsd_private.h")
 
 
 def test_every_declared_symbol_is_exported():
@@ -26,7 +29,31 @@ def test_every_declared_symbol_is_exported():
         assert ref in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert len(names) >= 40
+    assert 40 <= len(names) <= 58          # the reference has 18; tuning / test plumbing is not public API
+
+
+def test_the_library_exports_nothing_that_no_header_declares():
+    """Public API = include/pgsd.h; what tests, tools and the binding reach besides is declared in
+    csrc/pgsd_private.h; nothing else is exported under the pgsd_ prefix."""
+    import subprocess
+    lib = product.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    exported = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"
+                and ln.split()[2].startswith("pgsd_")}
+    public, private = set(declared_symbols()), set(declared_symbols(PRIVATE_HEADER))
+    assert not (public & private)
+    assert exported == public | private, sorted(exported ^ (public | private))
+
+
+def test_abi_version_is_exported_and_checked_by_the_bindings():
+    """entry points changed signature in place between rounds; bindings that resolve symbols at run time
+    compare pgsd_abi_version() with the PGSD_ABI_VERSION they were written against."""
+    from pgsd import _lib
+    hdr = open(os.path.join(product.ROOT, "include", "pgsd.h")).read()
+    declared = int(re.search(r"#define PGSD_ABI_VERSION (\d+)u", hdr).group(1))
+    assert _lib.lib.pgsd_abi_version() == declared == _lib.ABI_VERSION
+    src = open(os.path.join(product.ROOT, "pgsd-sph_amd", "pgsd", "_fl.pyx")).read()
+    assert "C.pgsd_abi_version() != C.PGSD_ABI_VERSION" in src
 
 
 def test_struct_layouts_match_the_format():
@@ -47,7 +74,8 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     assert _lib.lib.pgsd_pack_fields(1, job, 16, None, None) == _lib.ERROR_NO_DEVICE
     assert "no HIP device" in _lib.last_error()
     ws = ctypes.c_uint64(0)
-    assert _lib.lib.pgsd_select_rows(None, 0, None, ctypes.byref(ws), ctypes.byref(ws), None) == _lib.ERROR_NO_DEVICE
+    assert _lib.lib.pgsd_select_rows(None, 0, None, ctypes.byref(ws), None) == _lib.ERROR_NO_DEVICE
+    assert _lib.lib.pgsd_device_alloc(-1, 64, None, 0) is None and "no HIP device" in _lib.last_error()
 
 
 def test_device_write_without_gpu_raises(tmp_gsd):

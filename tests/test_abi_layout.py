@@ -14,6 +14,7 @@ import subprocess
 import product
 
 HEADER = os.path.join(product.ROOT, "include", "pgsd.h")
+PRIVATE = os.path.join(product.CSRC, "pgsd_private.h")       # bare-kernel job structs (tests, tools, the binding)
 
 # struct in the header -> ctypes.Structure in pgsd/_lib.py
 TWINS = {
@@ -28,7 +29,7 @@ TWINS = {
 def header_structs(text=None):
     """{struct name: [field names in declaration order]} parsed from the header's text."""
     if text is None:
-        text = open(HEADER).read()
+        text = open(HEADER).read() + open(PRIVATE).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     out = {}
@@ -51,7 +52,7 @@ def header_structs(text=None):
 
 def compiler_layout(structs, header_dir, tmp_path):
     """{struct: (sizeof, [(field, offset, size)])} as gcc lays the header's structs out."""
-    lines = ['#include "pgsd.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {"]
+    lines = ['#include "pgsd_private.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {"]
     for sname, fields in structs.items():
         lines.append('printf("S %s %%zu\\n", sizeof(struct %s));' % (sname, sname))
         for f in fields:
@@ -100,7 +101,11 @@ def mismatches(layout):
 def test_every_struct_of_the_header_matches_its_ctypes_twin(tmp_path):
     structs = header_structs()
     assert set(structs) == set(TWINS), sorted(set(structs) ^ set(TWINS))
-    layout = compiler_layout(structs, os.path.dirname(HEADER), tmp_path)
+    inc = tmp_path / "both"
+    inc.mkdir()
+    for h in (HEADER, PRIVATE):
+        (inc / os.path.basename(h)).write_text(open(h).read())
+    layout = compiler_layout(structs, str(inc), tmp_path)
     assert layout["pgsd_header"][0] == 256 and layout["pgsd_index_entry"][0] == 32       # on-disk structs
     assert not mismatches(layout), "\n".join(mismatches(layout))
 
@@ -108,15 +113,18 @@ def test_every_struct_of_the_header_matches_its_ctypes_twin(tmp_path):
 def test_a_field_inserted_into_the_header_is_noticed(tmp_path):
     """The check has teeth: a header with one more member in pgsd_handle / pgsd_pack_job / a new struct fails."""
     text = open(HEADER).read()
+    private = open(PRIVATE).read()
     inc = tmp_path / "inc"
     inc.mkdir()
     for needle, extra, expect in (
             ("        uint64_t cur_frame;\n", "        uint32_t sneaked_in;\n", "pgsd_handle"),
             ("        void* dst;         /* device pointer, N*M elements of dst_type", "        uint64_t sneaked_in;\n", "pgsd_pack_job"),
             ("    struct pgsd_device_stats\n", "    struct pgsd_new_thing { int a; };\n", "pgsd_new_thing")):
-        assert needle in text
+        assert needle in text or needle in private
         mutated = text.replace(needle, extra + needle, 1)
+        mutated_private = private.replace(needle, extra + needle, 1)
         (inc / "pgsd.h").write_text(mutated)
-        layout = compiler_layout(header_structs(mutated), str(inc), tmp_path)
+        (inc / "pgsd_private.h").write_text(mutated_private)
+        layout = compiler_layout(header_structs(mutated + mutated_private), str(inc), tmp_path)
         bad = mismatches(layout)
         assert any(expect in b for b in bad), (expect, bad)

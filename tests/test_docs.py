@@ -25,7 +25,7 @@ def test_files_named_in_the_documents_exist():
         text = open(os.path.join(ROOT, doc)).read()
         for tok in candidates(text, doc):
             path = os.path.join(ROOT, tok)
-            if tok.startswith("oracle/_ref") or tok.startswith("pgsd-sph_amd/csrc/build") or tok.endswith(".so"):
+            if tok.startswith("oracle/_ref") or tok.startswith("pgsd-sph_amd/csrc/build") or tok.startswith("tests/build") or tok.endswith(".so"):
                 continue                      # built artefacts, not in the tree
             if not os.path.exists(path):
                 missing.append((doc, tok))

@@ -274,7 +274,7 @@ def _bad_args_rank(rank, shm, path, batched, q):
         sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
         from pgsd import _lib as L
         import pgsd.fl as F
-        assert L.lib.pgsd_comm_init_shm(shm.encode(), rank, 2) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, 2)
         f = F.open(path, "w", application="app", schema="hoomd", schema_version=[1, 4])
         f.frame_exchange = batched
         h = f._h()
@@ -422,7 +422,7 @@ def _declared_bad_rank(rank, shm, path, q):
         sys.path.insert(0, os.path.join(root, "pgsd-sph_amd"))
         from pgsd import _lib as L
         import pgsd.fl as F
-        assert L.lib.pgsd_comm_init_shm(shm.encode(), rank, 2) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, 2)
         f = F.open(path, "w", application="app", schema="hoomd", schema_version=[1, 4])
         f.set_partition([5, 5])
         h = f._h()

@@ -167,7 +167,7 @@ def _union_rank(rank, P, shm, path, counts, q):
         import pgsd.fl as fl
         from pgsd import _lib
         import test_gpu_config4 as me
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         _t.cuda.set_device(0)
         row0 = int(sum(counts[:rank]))
         n = counts[rank]
@@ -356,7 +356,7 @@ def _append_rank(rank, P, shm, path, q):
         from pgsd import _lib
         import test_gpu_config4 as me
         import test_hoomd_append_oracle as A
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         _t.cuda.set_device(0)
         t = hoomd.open(path, "w")
         for g in A.global_frames():

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "thread_ranks_worker.py")
-FAKE = os.path.join(product.CSRC, "build", "libpgsd_fake_rccl.so")
+FAKE = os.path.join(product.TBUILD, "libpgsd_fake_rccl.so")
 
 
 def run_worker(kind, P, path, what):

@@ -41,7 +41,9 @@ def test_compare_and_copy_staged_against_numpy(N, tmp_gsd):
         refs = f.copy_staged(t, 0, [p.nbytes for p in packed])
         assert f.compare_staged(t, 0, refs) == [True] * 4               # a chunk equals its own copy
         for r, p in zip(refs, packed):
-            assert r.cpu().numpy().tobytes() == p.tobytes()             # ... which is the packed chunk
+            assert isinstance(r, fl.DeviceBuffer)                       # the library's own device memory (no torch)
+            assert r.to_host().tobytes() == p.tobytes()                 # ... which holds the packed chunk
+            assert torch.as_tensor(r, device="cuda").cpu().numpy().tobytes() == p.tobytes()   # __cuda_array_interface__
         f.write_staged(t, 0, 4, offset=np.array([N]))
         with pytest.raises(RuntimeError):
             f.compare_staged(t, 0, refs)                                # written chunks are gone
@@ -56,7 +58,7 @@ def test_compare_and_copy_staged_against_numpy(N, tmp_gsd):
         assert f.compare_staged(t, 1, [None, refs[2]]) == [False, False]
         # a reference at an odd address: the byte-wise road of the kernel
         odd = torch.empty(packed[3].nbytes + 4, dtype=torch.uint8, device="cuda")[4:]
-        odd.copy_(refs[3])
+        odd.copy_(torch.as_tensor(refs[3], device="cuda"))
         assert odd.data_ptr() % 16 != 0
         assert f.compare_staged(t, 3, [odd]) == [True]
         odd[-1] ^= 1
@@ -123,7 +125,7 @@ def test_append_elides_static_gpu_arrays_like_host_arrays(N, tmp_path):
             for args in frames:
                 t.append(_frame(hoomd, fl, *args, on_gpu, keep))
             if on_gpu:
-                assert not t._dev_dynamic and not t._dev_off
+                assert not t._dev_off
                 assert set(t._dev_ref) == {"particles/" + n for n in ("position", "typeid", "velocity", "mass", "density")}
     with open(a, "rb") as fa, open(b, "rb") as fb:
         assert fa.read() == fb.read()
@@ -140,29 +142,23 @@ def test_append_elides_static_gpu_arrays_like_host_arrays(N, tmp_path):
                 assert getattr(fr.particles, name).tobytes() == want.tobytes(), (k, name)
 
 
-def test_once_mode_stops_comparing_an_array_that_differed(tmp_path):
-    """`device_elision = 'once'` (the default of round 3): an array that differed from frame 0 once is written from
-    then on without a comparison -- the density that differs in frame 2 only is written in frames 3 and 4 too, where
-    the host path (and the default mode) elide it; the reader gets the same values either way."""
+def test_once_mode_is_gone(tmp_path):
+    """Round 3's `device_elision = 'once'` shortcut (stop comparing an array once it differed) was removed in round 5:
+    any truthy value is the one remaining mode -- every array compared in every frame -- so the density that differs in
+    frame 2 only is elided again in frames 3 and 4, as the host path elides it."""
     import pgsd.fl as fl
     import pgsd.hoomd as hoomd
     frames = _trajectory(np.random.default_rng(5), 3000, 5)
     path, keep = str(tmp_path / "gpu.gsd"), []
     with hoomd.open(path, "w") as t:
         t.device_elision = 'once'
+        assert not hasattr(t, "_dev_dynamic")
         for k, args in enumerate(frames):
             t.append(_frame(hoomd, fl, *args, True, keep))
-            if k == 1:
-                assert t._dev_dynamic == {"particles/position", "particles/velocity"}
-                assert set(t._dev_ref) == {"particles/typeid", "particles/mass", "particles/density"}
-        assert "particles/density" in t._dev_dynamic and not t._dev_off
     with hoomd.open(path, "r") as t:
         f = t.file
         assert [f.chunk_exists(k, "particles/typeid") for k in range(5)] == [True, False, False, False, False]
-        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, True, True]
-        for k, (step, pos, tid, mass, vel, dens) in enumerate(frames):
-            for name, want in (("position", pos), ("typeid", tid), ("mass", mass), ("velocity", vel), ("density", dens)):
-                assert getattr(t[k].particles, name).tobytes() == want.tobytes(), (k, name)
+        assert [f.chunk_exists(k, "particles/density") for k in range(5)] == [True, False, True, False, False]
 
 
 def test_append_device_elision_off_writes_everything(tmp_path):
@@ -261,12 +257,12 @@ def _append_rank(rank, P, shm, path, q):
         import test_gpu_config4 as C4
         import test_gpu_elision as me
         import test_hoomd_append_oracle as A
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         _t.cuda.set_device(0)
         t = hoomd.open(path, "w")
         for g in me._one_sided_frames():
             t.append(C4._device_frame(hoomd, fl, g, A.partition(g["n"], P), rank))
-        dyn = sorted(t._dev_dynamic)
+        dyn = []                        # (round 3's 'once' mode kept a set of arrays taken off the comparisons here)
         t.close()
         _lib.lib.pgsd_comm_finalize()
         q.put((rank, "ok", dyn))
@@ -314,7 +310,7 @@ def _reopen_rank(rank, P, shm, path, explicit, q):
         import pgsd.hoomd as hoomd
         from pgsd import _lib
         import test_gpu_elision as me
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         _t.cuda.set_device(0)
         counts = [700, 300]
         row0 = sum(counts[:rank])
@@ -419,7 +415,7 @@ def _random_rank(rank, P, shm, path, seed, q):
         from pgsd import _lib
         import test_gpu_config4 as C4
         import test_hoomd_append_oracle as A
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         _t.cuda.set_device(0)
         t = hoomd.open(path, "w")
         for k, g in enumerate(A.random_frames(seed, P)):
@@ -619,7 +615,7 @@ def test_four_ranks_as_threads_append_through_pgsd_hoomd(kind, tmp_path):
     env.pop("PGSD_RCCL_LIBRARY", None)
     if kind == "rccl":
         product.build()
-        env.update(PGSD_RCCL_LIBRARY=os.path.join(product.CSRC, "build", "libpgsd_fake_rccl.so"), PGSD_FAKE_RCCL_SYNC="1")
+        env.update(PGSD_RCCL_LIBRARY=os.path.join(product.TBUILD, "libpgsd_fake_rccl.so"), PGSD_FAKE_RCCL_SYNC="1")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hoomd_threads_worker.py")
     p = subprocess.run([sys.executable, worker, kind, str(P), str(seed), mine], env=env, capture_output=True, text=True,
                        timeout=400)
@@ -643,7 +639,7 @@ def test_exact_mode_elides_an_array_that_returns_to_frame_0(tmp_path):
             for args in frames:
                 t.append(_frame(hoomd, fl, *args, on_gpu, keep))
             if on_gpu:
-                assert not t._dev_dynamic and len(t._dev_ref) == 5
+                assert len(t._dev_ref) == 5
     with open(a, "rb") as fa, open(b, "rb") as fb:
         assert fa.read() == fb.read()
     with hoomd.open(a, "r") as t:

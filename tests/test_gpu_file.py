@@ -136,7 +136,7 @@ def _rank_main(rank, P, shm, path, counts, seed, q, async_seal=False, batched=Fa
         import torch
         import pgsd.fl as fl
         from pgsd import _lib
-        assert _lib.lib.pgsd_comm_init_shm(shm.encode(), rank, P) == 0
+        __import__("pgsd.dist").dist.init_shm(shm, rank, P)
         torch.cuda.set_device(0)
         n = counts[rank]
         row0 = int(sum(counts[:rank]))
@@ -265,7 +265,7 @@ def test_rccl_communicator_single_rank():
     import pgsd.dist as pdist
     uid = (ctypes.c_uint8 * 128)()
     assert _lib.lib.pgsd_comm_rccl_unique_id(uid) == 0, _lib.last_error()
-    assert _lib.lib.pgsd_comm_init_rccl(uid, 0, 1, 0) == 0, _lib.last_error()
+    assert pdist.init_rccl(bytes(uid), 0, 1, 0) == 0, _lib.last_error()
     try:
         counts, row0, n_global = pdist.partition_rows(4242)
         assert list(counts) == [4242] and row0 == 0 and n_global == 4242

@@ -22,7 +22,7 @@ import product
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAKE = os.path.join(product.CSRC, "build", "libpgsd_fake_rccl.so")
+FAKE = os.path.join(product.TBUILD, "libpgsd_fake_rccl.so")
 WRITE_EXE = os.path.join(product.CSRC, "build", "benchmark_write")
 READ_EXE = os.path.join(product.CSRC, "build", "benchmark_read")
 

@@ -50,7 +50,7 @@ def test_product_with_batched_frame_exchange_matches_reference_file(name, P, mod
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
-MPI_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_mpi")
+MPI_DRIVER = os.path.join(product.TBUILD, "scenario_driver_mpi")
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +59,7 @@ def mpi_driver():
     if not (os.path.exists(MPIEXEC) and os.path.exists("/opt/conda/include/mpi.h")):
         pytest.skip("no MPI installation in this image")
     product.build()
-    r = product.locked_make(["-C", product.CSRC, "mpi"], check=False, capture_output=True)
+    r = product.locked_make(["-C", product.TESTS, "mpi"], check=False, capture_output=True)
     if r.returncode != 0:
         pytest.skip("cannot link against MPI: " + r.stderr.decode()[-300:])
     return MPI_DRIVER

@@ -10,11 +10,11 @@ import pytest
 import product
 import scenario as S
 
-ASAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_asan")
+ASAN_DRIVER = os.path.join(product.TBUILD, "scenario_driver_asan")
 
 
 def _make(target):
-    return product.locked_make(["-C", product.CSRC, target], check=False, capture_output=True)
+    return product.locked_make(["-C", product.TESTS, target], check=False, capture_output=True)
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +67,7 @@ def test_local_reads_are_sanitizer_clean(asan_driver, tmp_path):
         assert a.read() == b.read()
 
 
-TSAN_DRIVER = os.path.join(product.CSRC, "build", "scenario_driver_tsan")
+TSAN_DRIVER = os.path.join(product.TBUILD, "scenario_driver_tsan")
 
 BIG_CHUNKS = """create app hoomd 1 4 rw 0
 seed 5

@@ -25,7 +25,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_overlap -- python3 $R/tools/overlap_probe.py --frames 16 > $O/overlap_under_rocprof.jsonl 2> $O/stats_overlap.err
 # full-size eight-rank runs (the tests' worker), for the record
 for what in config3 config4; do
-  PGSD_RCCL_LIBRARY=$R/pgsd-sph_amd/csrc/build/libpgsd_fake_rccl.so PGSD_FAKE_RCCL_SYNC=1 timeout -k 10 300 python3 $R/tests/fullsize_ranks_worker.py rccl 8 10000000 $what /dev/shm 2>/dev/null | grep RESULT >> $O/fullsize_eight_ranks.txt
+  PGSD_RCCL_LIBRARY=$R/tests/build/libpgsd_fake_rccl.so PGSD_FAKE_RCCL_SYNC=1 timeout -k 10 300 python3 $R/tests/fullsize_ranks_worker.py rccl 8 10000000 $what /dev/shm 2>/dev/null | grep RESULT >> $O/fullsize_eight_ranks.txt
   timeout -k 10 300 python3 $R/tests/fullsize_ranks_worker.py shm 8 10000000 $what /dev/shm 2>/dev/null | grep RESULT >> $O/fullsize_eight_ranks.txt
 done
 ls $O

@@ -10,7 +10,7 @@ rm -rf $O; mkdir -p $O; cd $O
 B="python3 $R/bench.py --particles 5000000 --steps 8 --warmup 2 --traffic off --rehearse-shared-gpu"
 for n in 2 4; do
   timeout -k 10 240 $B --gpus $n > shared_gpu_$n.json 2> shared_gpu_$n.err
-  PGSD_RCCL_LIBRARY=$R/pgsd-sph_amd/csrc/build/libpgsd_fake_rccl.so timeout -k 10 240 $B --gpus $n > rccl_glue_$n.json 2> rccl_glue_$n.err
+  PGSD_RCCL_LIBRARY=$R/tests/build/libpgsd_fake_rccl.so timeout -k 10 240 $B --gpus $n > rccl_glue_$n.json 2> rccl_glue_$n.err
 done
 timeout -k 10 240 $B --gpus 2 --declared-partition --no-cpu-baseline > declared_2.json 2> declared_2.err
 python3 - <<'PY'
