@@ -118,7 +118,7 @@ int agree_status(Impl* s, int local_rc, bool check_state)
 // fresh-file skeleton, pgsd.c:1414-1474 (rank 0 only)
 int initialize_file(int fd, const char* application, const char* schema, uint32_t schema_version)
     {
-    if (ftruncate(fd, 0) != 0)
+    if (io_truncate(fd, 0) != 0)
         return PGSD_ERROR_IO;
     std::vector<char> img(sizeof(pgsd_header) + INITIAL_INDEX_SIZE * sizeof(pgsd_index_entry)
                               + INITIAL_NAME_BUFFER_SIZE,
@@ -186,10 +186,9 @@ int initialize_handle(Impl* s)
     if (s->header.pgsd_version >= make_version(3, 0))
         return PGSD_ERROR_INVALID_PGSD_FILE_VERSION;
 
-    struct stat st;
-    if (fstat(s->fd, &st) != 0)
+    s->file_size = io_file_size(s->fd);
+    if (s->file_size < 0)
         return PGSD_ERROR_IO;
-    s->file_size = (long long)st.st_size;
 
     // pgsd.c:1558-1562; the products are formed so that a damaged header cannot wrap them around
     if (s->header.namelist_location > (uint64_t)s->file_size
@@ -278,7 +277,7 @@ void destroy_impl(Impl* s)
     if (s->pool)
         writer_pool_destroy(s->pool);
     if (s->fd >= 0)
-        close(s->fd);
+        io_close(s->fd);
     delete s;
     }
 
@@ -412,10 +411,10 @@ int expand_file_index(Impl* s, size_t size_required, int* local_rc)
     uint64_t eof = 0;
     if (s->rank == 0)
         {
-        struct stat st;
-        if (fstat(s->fd, &st) != 0)
+        const long long size = io_file_size(s->fd); // the true EOF (MPI_File_get_size, pgsd.c:1015)
+        if (size < 0)
             *local_rc = PGSD_ERROR_IO;
-        eof = (uint64_t)st.st_size;
+        eof = size < 0 ? 0 : (uint64_t)size;
         }
     std::vector<uint64_t> all;
     int rc = s->allgather_u64(eof, all);
@@ -775,7 +774,7 @@ static int create_and_open(const pgsd_comm* on, struct pgsd_handle* handle, cons
     int rc = PGSD_SUCCESS;
     if (s->rank == 0)
         {
-        s->fd = open(fname, O_RDWR | O_CREAT | (exclusive_create ? O_EXCL : 0), 0644);
+        s->fd = io_open(fname, O_RDWR | O_CREAT | (exclusive_create ? O_EXCL : 0), 0644);
         if (s->fd < 0)
             rc = PGSD_ERROR_IO;
         else
@@ -784,7 +783,7 @@ static int create_and_open(const pgsd_comm* on, struct pgsd_handle* handle, cons
     rc = agree_status(s, rc);
     if (rc == PGSD_SUCCESS && s->rank != 0)
         {
-        s->fd = open(fname, O_RDWR);
+        s->fd = io_open(fname, O_RDWR, 0);
         if (s->fd < 0)
             rc = PGSD_ERROR_IO;
         }
@@ -827,7 +826,7 @@ static int open_existing(const pgsd_comm* on, struct pgsd_handle* handle, const 
     Impl* s = new_impl(on);
     s->flags = flags;
     int rc = PGSD_SUCCESS;
-    s->fd = open(fname, flags == PGSD_OPEN_READONLY ? O_RDONLY : O_RDWR);
+    s->fd = io_open(fname, flags == PGSD_OPEN_READONLY ? O_RDONLY : O_RDWR, 0);
     if (s->fd < 0)
         rc = PGSD_ERROR_IO;
     else
@@ -878,7 +877,7 @@ extern "C" int pgsd_close(struct pgsd_handle* handle)
     handle->file_index.data = NULL;
     handle->file_names.data.data = NULL;
     handle->fd = -1;
-    if (close(fd) != 0)
+    if (io_close(fd) != 0)
         return flush_rc != PGSD_SUCCESS ? flush_rc : PGSD_ERROR_IO;
     return flush_rc;
     }

@@ -904,7 +904,7 @@ class DevicePipeline
                 size_t got = 0;
                 while (got < bytes)
                     {
-                    ssize_t r = pread(m_fd, host + got, bytes - got, (off_t)(file_offset + (long long)got));
+                    ssize_t r = io_pread(m_fd, host + got, bytes - got, file_offset + (long long)got);
                     if (r < 0 && errno == EINTR)
                         continue;
                     if (r <= 0)
@@ -1543,7 +1543,7 @@ class DevicePipeline
             size_t got = 0;
             while (got < n)
                 {
-                ssize_t r = pread(m_fd, s.host + got, n - got, (off_t)(foff + (long long)got));
+                ssize_t r = io_pread(m_fd, s.host + got, n - got, foff + (long long)got);
                 if (r < 0 && errno == EINTR)
                     continue;
                 if (r <= 0)

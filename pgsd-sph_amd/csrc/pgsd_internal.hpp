@@ -77,6 +77,16 @@ inline int comm_barrier(const pgsd_comm& c)
     return c.allgather(c.ctx, &one, all.data(), 1) == 0 ? PGSD_SUCCESS : PGSD_ERROR_COMM;
     }
 
+// ---- file back ends (pgsd_io.cpp): POSIX, or the reference's own MPI-IO calls with PGSD_IO=mpiio.  The descriptor of
+// io_open is what every other io_* call (and pwrite_full / pread_some below, which sit on them) takes.
+int io_open(const char* path, int oflags, int mode);
+int io_close(int fd);
+int io_truncate(int fd, long long size);
+long long io_file_size(int fd); // -1 + errno
+ssize_t io_pwrite(int fd, const void* buf, size_t bytes, long long offset);
+ssize_t io_pread(int fd, void* buf, size_t bytes, long long offset);
+const char* io_backend_name(); // "posix" | "mpiio"
+
 // ---- host IO: a pool of pwrite threads shared by the host and the device path ----
 class WriterPool;
 WriterPool* writer_pool_create(unsigned n_threads, const cpu_set_t* cpus = nullptr);

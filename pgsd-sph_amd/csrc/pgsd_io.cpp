@@ -1,15 +1,21 @@
-// pgsd_io.cpp -- positional file IO standing in for the reference's MPI-IO calls
+// pgsd_io.cpp -- positional file IO at the offsets of the reference's MPI-IO calls
 // (MPI_File_write_at pgsd.c:2229/1154/2032, MPI_File_read_at pgsd.c:651/1559/2534).
-// Each rank writes its own byte range with pwrite at the offset the reference computes.
+// Each rank writes its own byte range at the offset the reference computes, through one of two back ends behind the
+// io_* functions below: POSIX pwrite / pread (the default), or -- PGSD_IO=mpiio -- the reference's own
+// MPI_File_write_at / MPI_File_read_at, reached through the optional plugin libpgsd_amd_mpiio.so
+// (pgsd_mpiio_plugin.h; the library itself does not link MPI).  Same bytes at the same offsets either way.
 // The small thread pool here carries the device pipeline's writer and reader threads.  For
 // WRITES one thread per file is the measured optimum on the target boxes (buffered writes
 // serialise on the file's inode lock: profiles/r01_io_probe*.log); page-cache READS take no
 // exclusive lock and scale with threads.
 #include "pgsd_internal.hpp"
+#include "pgsd_mpiio_plugin.h"
 
+#include <atomic>
 #include <cctype>
 #include <cerrno>
 #include <cstdio>
+#include <cstring>
 #include <pthread.h>
 #include <sched.h>
 #include <string>
@@ -18,6 +24,10 @@
 #include <sys/uio.h>
 #include <condition_variable>
 #include <deque>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <map>
+#include <sys/stat.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -25,12 +35,196 @@
 
 namespace pgsd_amd
     {
+// ------------------------------------------------------------------ file back ends
+namespace
+    {
+struct MpiFiles
+    {
+    std::mutex lock; // serialises every call into the plugin: MPI_THREAD_SERIALIZED is all the caller must provide
+    int mode = -1;   // -1: PGSD_IO not looked at yet, 0: POSIX, 1: MPI-IO
+    bool loaded = false;
+    pgsd_mpiio_api api {};
+    std::map<int, void*> files; // descriptor -> the plugin's file handle
+    };
+MpiFiles g_mpi;
+std::atomic<int> g_mpi_open {0}; // number of MPI-IO files: the POSIX back end never takes the lock
+
+// the plugin lies next to this library unless PGSD_MPIIO_LIBRARY names another build (another MPI)
+bool load_mpiio_plugin()
+    {
+    if (g_mpi.loaded)
+        return true;
+    std::string path;
+    if (const char* e = getenv("PGSD_MPIIO_LIBRARY"))
+        path = e;
+    else
+        {
+        Dl_info info;
+        if (dladdr((void*)&load_mpiio_plugin, &info) && info.dli_fname)
+            {
+            path = info.dli_fname;
+            const size_t slash = path.rfind('/');
+            path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "libpgsd_amd_mpiio.so";
+            }
+        else
+            path = "libpgsd_amd_mpiio.so";
+        }
+    void* lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib)
+        {
+        set_last_error(std::string("PGSD_IO=mpiio: cannot load the MPI-IO back end (build it with `make -C pgsd-sph_amd/csrc mpiio`): ")
+                       + dlerror());
+        return false;
+        }
+    auto entry = (int (*)(pgsd_mpiio_api*))dlsym(lib, "pgsd_mpiio_plugin");
+    if (!entry)
+        {
+        set_last_error("PGSD_IO=mpiio: " + path + " has no pgsd_mpiio_plugin");
+        return false;
+        }
+    if (entry(&g_mpi.api) != 0)
+        {
+        set_last_error(std::string("PGSD_IO=mpiio: ") + (g_mpi.api.last_error ? g_mpi.api.last_error() : "the back end refused"));
+        return false;
+        }
+    g_mpi.loaded = true;
+    return true;
+    }
+
+// run f(plugin handle of fd) under the plugin lock when fd is an MPI-IO file; false: fd is a POSIX file
+template<class F> bool with_mpi_file(int fd, F f)
+    {
+    if (g_mpi_open.load(std::memory_order_acquire) == 0)
+        return false;
+    std::lock_guard<std::mutex> guard(g_mpi.lock);
+    auto it = g_mpi.files.find(fd);
+    if (it == g_mpi.files.end())
+        return false;
+    f(it->second);
+    return true;
+    }
+    } // namespace
+
+const char* io_backend_name()
+    {
+    std::lock_guard<std::mutex> guard(g_mpi.lock);
+    if (g_mpi.mode < 0)
+        {
+        const char* e = getenv("PGSD_IO");
+        g_mpi.mode = (e && strcmp(e, "mpiio") == 0) ? 1 : 0;
+        if (e && *e && strcmp(e, "mpiio") != 0 && strcmp(e, "posix") != 0)
+            fprintf(stderr, "pgsd_amd: PGSD_IO=%s is neither posix nor mpiio: posix\n", e);
+        }
+    return g_mpi.mode == 1 ? "mpiio" : "posix";
+    }
+
+// open(2); with PGSD_IO=mpiio the file is ALSO opened through MPI-IO and every later io_* call on the descriptor
+// goes there (the descriptor stays the file's identity and what the advisory write lock is taken on)
+int io_open(const char* path, int oflags, int mode)
+    {
+    const int fd = open(path, oflags, mode);
+    if (fd < 0 || strcmp(io_backend_name(), "mpiio") != 0)
+        return fd;
+    std::lock_guard<std::mutex> guard(g_mpi.lock);
+    void* fh = nullptr;
+    if (!load_mpiio_plugin() || g_mpi.api.open(path, (oflags & O_ACCMODE) == O_RDONLY, &fh) != 0)
+        {
+        if (g_mpi.loaded)
+            set_last_error(std::string("PGSD_IO=mpiio: ") + g_mpi.api.last_error());
+        close(fd);
+        errno = EIO;
+        return -1;
+        }
+    g_mpi.files[fd] = fh;
+    g_mpi_open.fetch_add(1, std::memory_order_release);
+    return fd;
+    }
+
+int io_close(int fd)
+    {
+    int rc = 0;
+    bool mpi = false;
+        {
+        std::lock_guard<std::mutex> guard(g_mpi.lock);
+        auto it = g_mpi.files.find(fd);
+        if (it != g_mpi.files.end())
+            {
+            mpi = true;
+            rc = g_mpi.api.close(it->second);
+            g_mpi.files.erase(it);
+            g_mpi_open.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    const int crc = close(fd);
+    if (mpi && rc != 0)
+        {
+        errno = EIO;
+        return -1;
+        }
+    return crc;
+    }
+
+int io_truncate(int fd, long long size)
+    {
+    int rc = 0;
+    if (with_mpi_file(fd, [&](void* fh) { rc = g_mpi.api.set_size(fh, size); }))
+        {
+        if (rc != 0)
+            errno = EIO;
+        return rc;
+        }
+    return ftruncate(fd, (off_t)size);
+    }
+
+long long io_file_size(int fd)
+    {
+    long long size = -1;
+    if (with_mpi_file(fd, [&](void* fh) { size = g_mpi.api.get_size(fh); }))
+        {
+        if (size < 0)
+            errno = EIO;
+        return size;
+        }
+    struct stat st;
+    if (fstat(fd, &st) != 0)
+        return -1;
+    return (long long)st.st_size;
+    }
+
+// pwrite(2) / pread(2) semantics (bytes moved, -1 + errno) on either back end
+ssize_t io_pwrite(int fd, const void* buf, size_t bytes, long long offset)
+    {
+    long long n = -1;
+    if (with_mpi_file(fd, [&](void* fh) { n = g_mpi.api.write_at(fh, offset, buf, (long long)bytes); }))
+        {
+        if (n < 0)
+            {
+            set_last_error(std::string("PGSD_IO=mpiio: ") + g_mpi.api.last_error());
+            errno = EIO;
+            }
+        return (ssize_t)n;
+        }
+    return pwrite(fd, buf, bytes, (off_t)offset);
+    }
+
+ssize_t io_pread(int fd, void* buf, size_t bytes, long long offset)
+    {
+    long long n = -1;
+    if (with_mpi_file(fd, [&](void* fh) { n = g_mpi.api.read_at(fh, offset, buf, (long long)bytes); }))
+        {
+        if (n < 0)
+            errno = EIO;
+        return (ssize_t)n;
+        }
+    return pread(fd, buf, bytes, (off_t)offset);
+    }
+
 int pwrite_full(int fd, const void* buf, size_t bytes, long long offset)
     {
     const char* p = (const char*)buf;
     while (bytes > 0)
         {
-        ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
+        ssize_t w = io_pwrite(fd, p, bytes, offset);
         if (w < 0)
             {
             if (errno == EINTR)
@@ -89,6 +283,16 @@ int pwritev_locked(int fd, struct iovec* iov, int n, long long offset, bool shar
                 }
         }
     int rc = 0;
+    if (g_mpi_open.load(std::memory_order_acquire) != 0 && with_mpi_file(fd, [](void*) { }))
+        {
+        // MPI-IO has no gather write: one MPI_File_write_at per buffer, in file order
+        for (; n > 0 && rc == 0; iov++, n--)
+            {
+            rc = pwrite_full(fd, iov->iov_base, iov->iov_len, offset);
+            offset += (long long)iov->iov_len;
+            }
+        n = 0;
+        }
     while (n > 0)
         {
         ssize_t w = pwritev(fd, iov, n > 1024 ? 1024 : n, (off_t)offset);
@@ -128,7 +332,7 @@ void pread_some(int fd, void* buf, size_t bytes, long long offset)
     char* p = (char*)buf;
     while (bytes > 0)
         {
-        ssize_t r = pread(fd, p, bytes, (off_t)offset);
+        ssize_t r = io_pread(fd, p, bytes, offset);
         if (r <= 0)
             {
             if (r < 0 && errno == EINTR)

@@ -41,3 +41,14 @@ def pytest_configure(config):
 @pytest.fixture
 def tmp_gsd(tmp_path):
     return str(tmp_path / "out.gsd")
+
+
+@pytest.fixture(autouse=True)
+def _tuning_is_read_again():
+    """The library reads its PGSD_* tuning variables ONCE (csrc/pgsd_private.h: pgsd_reload_tuning).  Tests that set
+    them with monkeypatch (PGSD_PACK_KERNEL=tiles ...) need them read again -- before the test (its fixtures have set
+    them by the time it launches something) and after it (the next test gets the restored environment)."""
+    from pgsd import _lib
+    _lib.lib.pgsd_reload_tuning()
+    yield
+    _lib.lib.pgsd_reload_tuning()

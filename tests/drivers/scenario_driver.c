@@ -419,7 +419,11 @@ int main(int argc, char** argv)
     MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
     MPI_Comm_size(MPI_COMM_WORLD, &g_size);
 #elif defined(PGSD_DRIVER_MPI)
-    MPI_Init(NULL, NULL);
+    {
+    /* PGSD_IO=mpiio: the library's writer threads call into MPI-IO too (serialised by the library) */
+    int provided = 0;
+    MPI_Init_thread(NULL, NULL, MPI_THREAD_SERIALIZED, &provided);
+    }
     MPI_Comm_rank(MPI_COMM_WORLD, &g_rank);
     MPI_Comm_size(MPI_COMM_WORLD, &g_size);
     {

@@ -81,6 +81,55 @@ def test_product_under_mpiexec_matches_reference_file(mpi_driver, name, P, tmp_g
     assert [ln for ln in out.stdout.decode().splitlines() if ln.strip()] == S.read_log(golden[:-4] + ".log")
 
 
+@pytest.fixture(scope="module")
+def mpiio_plugin(mpi_driver):
+    r = product.locked_make(["-C", product.CSRC, "mpiio"], check=False, capture_output=True)
+    plugin = os.path.join(product.ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd_mpiio.so")
+    if r.returncode != 0 or not os.path.exists(plugin):
+        pytest.skip("cannot build the MPI-IO back end: " + r.stderr.decode()[-300:])
+    return plugin
+
+
+@pytest.mark.parametrize("name,P", S.golden_cases())
+def test_mpiio_back_end_under_mpiexec_matches_reference_file(mpi_driver, mpiio_plugin, name, P, tmp_gsd):
+    """PGSD_IO=mpiio: the bytes reach the file through the reference's own calls --
+    MPI_File_write_at / MPI_File_read_at / MPI_File_set_size / MPI_File_get_size at the offsets of pgsd.c:2229, 1154,
+    2032, 1289-1306, 1015, 2534 -- via the plugin libpgsd_amd_mpiio.so; the library's collectives go to MPI through
+    the communicator vtable.  All 48 reference-written goldens are reproduced under `mpiexec -n P`, reads and their
+    hashes included; the default (POSIX pwrite) is unchanged (every other test of this file)."""
+    import subprocess
+    golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
+    out = subprocess.run([MPIEXEC, "-n", str(P), mpi_driver, S.scenario_path(name), tmp_gsd],
+                         capture_output=True, timeout=300, env=dict(os.environ, PGSD_IO="mpiio"))
+    assert out.returncode == (1 if _fails_on_purpose(golden) else 0), out.stderr.decode()[-500:]
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        assert f.read() == g.read()
+    assert [ln for ln in out.stdout.decode().splitlines() if ln.strip()] == S.read_log(golden[:-4] + ".log")
+
+
+def test_mpiio_back_end_fails_loudly_without_its_plugin_or_without_mpi(mpi_driver, mpiio_plugin, tmp_gsd):
+    """No silent fall-back to pwrite: PGSD_IO=mpiio with a plugin that cannot be loaded, or in a process that never
+    initialised MPI (the plain driver), fails the create with the reason in the error string."""
+    import subprocess
+    scn = S.scenario_path("posvelid")
+    out = subprocess.run([MPIEXEC, "-n", "1", mpi_driver, scn, tmp_gsd], capture_output=True, timeout=120,
+                         env=dict(os.environ, PGSD_IO="mpiio", PGSD_MPIIO_LIBRARY="/nonexistent/libpgsd_amd_mpiio.so"))
+    assert out.returncode != 0 and b"rc=-1" in out.stdout          # PGSD_ERROR_IO from create, then everything fails
+    assert not os.path.exists(tmp_gsd) or os.path.getsize(tmp_gsd) == 0
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pgsd.fl as fl\n"
+            "from pgsd import _lib\n"
+            "try:\n"
+            "    fl.open(%r, 'w', application='a', schema='s', schema_version=[1, 0])\n"
+            "    print('OPENED')\n"
+            "except OSError as e:\n"
+            "    print('REFUSED', _lib.last_error())\n" % (os.path.join(product.ROOT, "pgsd-sph_amd"), tmp_gsd))
+    import sys
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PGSD_IO="mpiio"))
+    assert "REFUSED" in p.stdout and "MPI is not initialised" in p.stdout, (p.stdout, p.stderr[-1000:])
+
+
 @pytest.mark.parametrize("name", ["readback", "idxbuf", "vone_append"])
 def test_local_reads_on_one_rank_change_nothing(name, tmp_gsd, tmp_path):
     """pgsd_set_local_reads(1): a read drains this rank's own copies instead of running the reference's collective

@@ -151,6 +151,7 @@ def run(workload, N, iters, warmup, sleep_ms=0.0, variants=None):
             for kv in v.split("+"):
                 k, _, val = kv.partition("=")
                 os.environ[k] = val
+            _lib.lib.pgsd_reload_tuning()     # the library reads its tuning variables once (csrc/pgsd_private.h)
         evs[i][0].record()
         if KERNEL_ONLY:
             # the dispatches' own begin / end stamps (what rocprofv3 reports): no launch latency in the figure
