@@ -416,8 +416,9 @@ LEG_ORDER = ["config2", "config4_sph", "config4_union", "config5_read", "gather_
 MARKER = "select_count_kernel"        # pgsd_select_rows: no leg uses it; one call separates two legs in the trace
 
 
-def pmc_child(out_path, N):
-    """Run under rocprofv3 --pmc: every leg's kernels a few times, a marker launch in front of each leg."""
+def pmc_child(out_path, N, reps=3):
+    """Run under rocprofv3 (--pmc passes of add_traffic; --kernel-trace --stats of tools/profile_legs.sh): every leg's
+    kernels `reps` times, a marker launch in front of each leg."""
     import numpy as np
     import torch
     import pgsd.fl as fl
@@ -425,7 +426,6 @@ def pmc_child(out_path, N):
     torch.cuda.set_device(0)
     flags = torch.ones(4096, dtype=torch.uint8, device="cuda")
     launches = {}
-    reps = 3
     g = torch.Generator(device="cuda").manual_seed(1234)
 
     def marker():
@@ -436,9 +436,14 @@ def pmc_child(out_path, N):
     for leg in LEG_ORDER:
         if leg == "config2":
             n = 1 << 20
-            fields, _, _, _, keep = make_fields("pvi", n, g, torch, np, fl, separate_id=True)
-            arr, k2 = pack_jobs(fields, n, torch, np, _lib)
-            run = lambda: timed_pack([arr], n, reps, 0, _lib)
+            keep, k2, sets = [], [], []
+            for _ in range(11):                # rotated like the leg itself: no launch re-reads the Infinity Cache
+                fields, _, _, _, k = make_fields("pvi", n, g, torch, np, fl, separate_id=True)
+                arr, kk = pack_jobs(fields, n, torch, np, _lib)
+                sets.append(arr)
+                keep.append(k)
+                k2.append(kk)
+            run = lambda: timed_pack(sets, n, reps, 0, _lib)
         elif leg in ("config4_sph", "config4_union"):
             fields, _, _, _, keep = make_fields(leg.split("_")[1], N, g, torch, np, fl)
             arr, k2 = pack_jobs(fields, N, torch, np, _lib)
@@ -572,13 +577,14 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--pmc-child", default=None, help="internal: run every leg's kernels under a counter pass")
+    ap.add_argument("--reps", type=int, default=3, help="--pmc-child: launches per leg")
     ap.add_argument("--particles", type=int, default=10_000_000)
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     if a.pmc_child:
-        pmc_child(a.pmc_child, a.particles)
+        pmc_child(a.pmc_child, a.particles, a.reps)
     else:
         legs, src = run_legs(a.particles, a.dir, None, traffic=not a.no_traffic,
                              only=[x for x in a.only.split(",") if x] or None)

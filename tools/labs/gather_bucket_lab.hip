@@ -55,11 +55,43 @@ typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
         } while (0)
 
 // ---------------------------------------------------------------- direct gather (baseline shape)
-template<int T, int U>
+template<int T, int U, bool SPLIT = false>
 __global__ __launch_bounds__(T) void direct_gather(const u32x4* __restrict__ pos, const u32x4* __restrict__ vel,
                                                     const uint32_t* __restrict__ order, uint64_t N, uint32_t* opos,
                                                     uint32_t* ovel, uint32_t* otid)
     {
+    if constexpr (SPLIT)
+        {
+        // blockIdx.y = source array: a wave keeps ONE random input stream open (the product's row kernel deals its
+        // workgroups to source arrays the same way)
+        const uint64_t base = (uint64_t)blockIdx.x * (T * U);
+        const u32x4* src = blockIdx.y ? vel : pos;
+        uint32_t* out = blockIdx.y ? ovel : opos;
+        uint32_t o[U];
+        u32x4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            {
+            const uint64_t t = base + (uint64_t)u * T + threadIdx.x;
+            o[u] = t < N ? __builtin_nontemporal_load(order + t) : 0u;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            p[u] = src[o[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            {
+            const uint64_t t = base + (uint64_t)u * T + threadIdx.x;
+            if (t < N)
+                {
+                u32x3 a = {p[u].x, p[u].y, p[u].z};
+                __builtin_nontemporal_store(a, (u32x3_a4*)(out + 3 * t));
+                if (blockIdx.y == 0)
+                    __builtin_nontemporal_store(p[u].w, otid + t);
+                }
+            }
+        return;
+        }
     const uint64_t base = (uint64_t)blockIdx.x * (T * U);
     uint32_t o[U];
     u32x4 p[U], v[U];
@@ -430,25 +462,43 @@ int main(int argc, char** argv)
             return ok;
         };
 
-        // ---- direct gather
-            {
-            constexpr int T = 256, U = 4;
-            const unsigned blocks = (unsigned)((N + T * U - 1) / (T * U));
+        // ---- direct gather, several launch shapes
+        auto direct = [&](auto launch, const char* name)
+        {
             clear_out();
-            direct_gather<T, U><<<blocks, T, 0, s>>>(dpos, dvel, dorder, N, opos, ovel, otid);
+            launch();
             CK(hipStreamSynchronize(s));
-            const bool ok = check("direct");
+            const bool ok = check(name);
             CK(hipEventRecord(e0, s));
             for (int r = 0; r < reps; r++)
-                direct_gather<T, U><<<blocks, T, 0, s>>>(dpos, dvel, dorder, N, opos, ovel, otid);
+                launch();
             CK(hipEventRecord(e1, s));
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("{\"lab\": \"gather_bucket\", \"N\": %llu, \"perm\": \"%s\", \"variant\": \"direct 256x4\", \"us\": %.1f, \"ok\": %s}\n",
-                   (unsigned long long)N, kind, ms * 1e3 / reps, ok ? "true" : "false");
+            printf("{\"lab\": \"gather_bucket\", \"N\": %llu, \"perm\": \"%s\", \"variant\": \"direct %s\", \"us\": %.1f, \"ok\": %s}\n",
+                   (unsigned long long)N, kind, name, ms * 1e3 / reps, ok ? "true" : "false");
             fflush(stdout);
-            }
+        };
+#define DIRECT(T, U)                                                                                                  \
+    direct([&]() { direct_gather<T, U><<<(unsigned)((N + T * U - 1) / (T * U)), T, 0, s>>>(dpos, dvel, dorder, N, opos, ovel, otid); }, \
+           #T "x" #U);
+#define DIRECT_SPLIT(T, U)                                                                                            \
+    direct([&]() { direct_gather<T, U, true><<<dim3((unsigned)((N + T * U - 1) / (T * U)), 2), T, 0, s>>>(dpos, dvel, dorder, N, opos, ovel, otid); }, \
+           #T "x" #U " split");
+        DIRECT(256, 4)
+        DIRECT(256, 2)
+        DIRECT(256, 8)
+        DIRECT(128, 4)
+        DIRECT(64, 4)
+        DIRECT(64, 8)
+        DIRECT(512, 4)
+        DIRECT(1024, 2)
+        DIRECT_SPLIT(256, 4)
+        DIRECT_SPLIT(256, 8)
+        DIRECT_SPLIT(128, 8)
+        DIRECT_SPLIT(64, 8)
+        DIRECT_SPLIT(512, 8)
         // ---- the product's kernel through the C ABI
         if (pack_fields)
             {
@@ -542,6 +592,8 @@ int main(int argc, char** argv)
         { bucket_pass2<512, 10><<<blocks, 512, 0, s>>>(ipos, ivel, itag, N, shift, G, opos, ovel, otid, derr); };
         auto p2_1024_12 = [&](unsigned blocks, uint32_t shift, uint32_t G)
         { bucket_pass2<1024, 12><<<blocks, 1024, 0, s>>>(ipos, ivel, itag, N, shift, G, opos, ovel, otid, derr); };
+        if (getenv("LAB_DIRECT_ONLY"))
+            continue;
         for (uint32_t shift : {13u, 14u, 15u, 16u})
             {
             two_pass(p1_1024x8, "p1 1024x8", 8192, p2_512_11, "p2 512", 11, shift, 512);
