@@ -188,6 +188,34 @@ def test_gather_in_tag_order(N, sdt, stride, M, ddt):
     check(out, G.oracle_pack(src, M, out_dtype=ddt, order=order))
 
 
+@pytest.mark.parametrize("N", [1, 2047, 2048, 2049, 300001])
+def test_gather_of_a_whole_frame_mixed_with_streamed_fields(N):
+    """A tag-ordered frame in one call: position.xyz + the type id in position.w (one source array, one index list),
+    velocity.xyz + mass out of a double4 array (f64 -> f32 on the way), a dense int32 array whose ROWS are gathered, a
+    second index list -- and two fields that are not gathered at all (another launch of the same call).  Every chunk
+    == oracle_pack_rows.  (Written for round 5's row-per-lane gather kernel, which lost its A/B against the LDS-tiled
+    gather -- profiles/r05_gather_cfg_ab.jsonl -- and was not kept; the case it pins is kernel-independent.)"""
+    rng = np.random.default_rng(N)
+    Nsrc = N + 5
+    pos = G.rand_array(rng, (Nsrc, 4), np.float32)
+    vel = G.rand_array(rng, (Nsrc, 4), np.float64)
+    body = G.rand_array(rng, (Nsrc, 1), np.int32)
+    img = G.rand_array(rng, (Nsrc, 3), np.int32)
+    order = rng.permutation(Nsrc)[:N].astype(np.uint32)
+    order2 = rng.permutation(Nsrc)[:N].astype(np.uint32)
+    dpos, dvel, dbody, dimg = dev(pos), dev(vel), dev(body), dev(img)
+    do, do2 = dev(order.view(np.int32)), dev(order2.view(np.int32))
+    spec = [(np.float32, 3, dpos, pos, 0, do, order, False), (np.uint32, 1, dpos, pos, 3, do, order, True),
+            (np.float32, 3, dvel, vel, 0, do, order, False), (np.float32, 1, dvel, vel, 3, do, order, False),
+            (np.int32, 1, dbody, body, 0, do, order, False), (np.int32, 3, dimg, img, 0, do2, order2, False),
+            (np.float32, 3, dpos, pos, 0, None, None, False), (np.int32, 1, dbody, body, 0, None, None, False)]
+    outs = [empty_out(N, M, dt) for dt, M, *_ in spec]
+    G.hip_pack([(o, dt, M, d, c0, dord, bc) for o, (dt, M, d, _, c0, dord, _, bc) in zip(outs, spec)], N)
+    for o, (dt, M, _, host, c0, _, ordr, bc) in zip(outs, spec):
+        src = host if ordr is not None else host[:N]
+        check(o, G.oracle_pack(src, M, col0=c0, out_dtype=dt, order=ordr, bitcast=bc))
+
+
 def test_unaligned_pointers_take_the_generic_kernel():
     N = 5003
     rng = np.random.default_rng(5)

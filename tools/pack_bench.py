@@ -66,11 +66,13 @@ def make_jobs(workload, N, gen):
                 (out(N, 3, f32), np.float32, 3, vel, 0, None, False),
                 (out(N, 1, i32), np.uint32, 1, tid, 0, None, False)]
         algo, moved = (24 + 24 + 4 + 28) * N, (32 + 32 + 4 + 28) * N
-    elif workload in ("gather", "gather_hilbert"):   # tag order through a permutation: uniformly random (adversarial),
+    elif workload in ("gather", "gather_hilbert", "gather_identity"):   # tag order through a permutation: uniformly random (adversarial),
         # or lattice-order tags over Hilbert-curve memory order (what HOOMD's SFC sorter leaves; bench_legs.hilbert_order)
         pos, vel = rnd((N, 4), f32), rnd((N, 4), f32)
         if workload == "gather":
             order = torch.randperm(N, generator=gen, device="cuda").to(i32)
+        elif workload == "gather_identity":     # right after initialisation: memory order IS tag order
+            order = torch.arange(N, device="cuda", dtype=i32)
         else:
             sys.path.insert(0, ROOT)
             import bench_legs
