@@ -175,7 +175,7 @@ static int rccl_wait_bounded(RcclCtx* c)
             if (g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(c->comm, &state) == ncclSuccess && state != ncclSuccess
                 && state != ncclInProgress)
                 return rccl_break(c, std::string("RCCL exchange failed asynchronously: ") + nccl_text(state));
-            if (el > c->timeout_s)
+            if (c->timeout_s > 0 && el > c->timeout_s)
                 {
                 char msg[200];
                 snprintf(msg, sizeof(msg),
@@ -368,9 +368,14 @@ static int rccl_open_comm(const void* unique_id_128, int rank, int size, int dev
     memcpy(&id, unique_id_128, sizeof(id));
     if (const char* t = getenv("PGSD_COMM_TIMEOUT_S"))
         {
+        // seconds; 0 (or "off" / "inf"): no deadline -- wait for a peer as long as MPI_Allgather would (a rank may be
+        // blocked on a slow file system or on the staging soft cap for longer than any fixed figure: ADVICE r4);
+        // RCCL's own asynchronous errors still end the wait
         const double v = atof(t);
         if (v > 0)
             c->timeout_s = v;
+        else if (strcmp(t, "0") == 0 || strcmp(t, "off") == 0 || strcmp(t, "inf") == 0)
+            c->timeout_s = 0;
         }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)

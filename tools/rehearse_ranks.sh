@@ -2,10 +2,10 @@
 # Multi-rank rehearsals of bench.py on a ONE-GPU box (the ranks share cuda:0 over a gloo group): 2 and 4 ranks with
 # torch.distributed callbacks, the same through the native RCCL back end's code over the tests' stand-in librccl
 # (asynchronous on the stream, ranks as processes), and a declared partition.  Not a measurement of RCCL: what runs here
-# is everything above the seven librccl calls.  Outputs: gpurun_out/r04/rehearse/*.json.
+# is everything above the seven librccl calls.  Outputs: gpurun_out/<tag>/rehearse/*.json (REHEARSE_TAG, default r05).
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04/rehearse
+O=$R/gpurun_out/${REHEARSE_TAG:-r05}/rehearse
 rm -rf $O; mkdir -p $O; cd $O
 B="python3 $R/bench.py --particles 5000000 --steps 8 --warmup 2 --traffic off --rehearse-shared-gpu"
 for n in 2 4; do
