@@ -121,9 +121,13 @@ PACK_KERNEL = "pack_rows_kernel"   # the dominant kernel of the default layout (
 
 
 def pack_source_sha256():
+    """Hash of the pack kernels' source: pgsd_pack.hip and the device helpers it shares (pgsd_kernels.hpp)."""
     import hashlib
-    with open(os.path.join(ROOT, "pgsd-sph_amd", "csrc", "pgsd_pack.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()
+    for name in ("pgsd_pack.hip", "pgsd_kernels.hpp"):
+        with open(os.path.join(ROOT, "pgsd-sph_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def pmc_pass(counter, child_args, timeout):
@@ -200,7 +204,7 @@ def traffic_from_file(N, args):
             tj = json.load(tf)
         if tj.get("particles") == N and args.schema == "pvi" and not args.separate_id:
             if tj.get("pack_source_sha256") != pack_source_sha256():
-                return None, "profiles/pack_traffic.json is older than pgsd_pack.hip: not reported"
+                return None, "profiles/pack_traffic.json is older than pgsd_pack.hip / pgsd_kernels.hpp: not reported"
             return tj["hbm_bytes_per_launch"], "file: profiles/pack_traffic.json (" + tj.get("source", "") + ")"
     except (OSError, ValueError, KeyError):
         pass

@@ -1,13 +1,10 @@
-// pgsd_pack.hip -- gfx950 (CDNA4 / MI355X) kernels of the snapshot pack path.
+// pgsd_pack.hip -- gfx950 (CDNA4 / MI355X) kernels of the snapshot PACK path and their launcher.
 //
 // pack:    chunk[i][c] = convert(src[(order ? order[i] : i) * stride + col0 + c])
 //          for every field of a frame, from HBM-resident particle arrays (HOOMD-style
 //          float4 / double4 / scalar arrays) into dense GSD chunk buffers.
-// unpack:  the inverse for restart reads, all chunks of a frame in one launch, whole destination
-//          rows assembled in registers where the launch restores every column of an array.
-// select:  stream compaction (filtered snapshots): wave ballot / popcount scans give each
-//          workgroup's count, a one-block scan turns counts into offsets (= per-chunk row
-//          and byte counts), a scatter pass writes the index list.
+// (unpack, the inverse for restart reads: pgsd_unpack.hip; chunk comparison, stream compaction and library-owned device
+//  memory: pgsd_select.hip; shared device helpers: pgsd_kernels.hpp.)
 //
 // The path is pure data movement, so the design target is the HBM roofline, not MFMA.  Two families:
 //
@@ -30,117 +27,10 @@
 // No reference counterpart exists (the reference has no device code); the
 // outputs are pinned by oracle_pack_rows() in oracle/pgsd_oracle.c and by the byte layout
 // of chunks in the golden files.
-#include "pgsd_internal.hpp"
-#include "pgsd_pack.hpp"
-#include "pgsd_private.h"
-
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <algorithm>
-#include <cstdlib>
-#include <cstdio>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <mutex>
-#include <vector>
+#include "pgsd_kernels.hpp"
 
 namespace pgsd_amd
     {
-#define PACK_THREADS 256
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------ device helpers
-
-template<int SSZ> __device__ __forceinline__ uint64_t lds_load(const char* p)
-    {
-    if constexpr (SSZ == 1)
-        return *(const uint8_t*)p;
-    else if constexpr (SSZ == 2)
-        return *(const uint16_t*)p;
-    else if constexpr (SSZ == 4)
-        return *(const uint32_t*)p;
-    else
-        return *(const uint64_t*)p;
-    }
-
-// one element, value semantics selected by `kind` (wave-uniform)
-template<int SSZ, int DSZ> __device__ __forceinline__ uint64_t convert_elem(uint64_t raw, uint32_t kind)
-    {
-    switch (kind)
-        {
-        default:
-        case PACK_BITS: // same width, narrowing, zero-extension, bitcast: low bytes
-            return raw;
-        case PACK_SEXT:
-            {
-            if constexpr (SSZ == 1)
-                return (uint64_t)(int64_t)(int8_t)raw;
-            else if constexpr (SSZ == 2)
-                return (uint64_t)(int64_t)(int16_t)raw;
-            else if constexpr (SSZ == 4)
-                return (uint64_t)(int64_t)(int32_t)raw;
-            else
-                return raw;
-            }
-        case PACK_F2F:
-            {
-            if constexpr (SSZ == 8 && DSZ == 4)
-                return (uint64_t)__float_as_uint((float)__longlong_as_double((long long)raw)); // RNE
-            else if constexpr (SSZ == 4 && DSZ == 8)
-                return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)raw));
-            else
-                return raw;
-            }
-        case PACK_U2F:
-            {
-            if constexpr (DSZ == 4)
-                return (uint64_t)__float_as_uint((float)(uint32_t)raw);
-            else
-                return (uint64_t)__double_as_longlong((double)(uint32_t)raw);
-            }
-        case PACK_S2F:
-            {
-            int32_t v;
-            if constexpr (SSZ == 1)
-                v = (int8_t)raw;
-            else if constexpr (SSZ == 2)
-                v = (int16_t)raw;
-            else
-                v = (int32_t)raw;
-            if constexpr (DSZ == 4)
-                return (uint64_t)__float_as_uint((float)v);
-            else
-                return (uint64_t)__double_as_longlong((double)v);
-            }
-        }
-    }
-
-// LDS image skew: 16 bytes of padding after every 128 bytes.  A staged float4 tile read back
-// column-wise (position.xyz with stride 16/3 words, the w column with stride 16 words) hits the
-// same few of the 32 banks: 6-way conflicts for xyz, 16-way for w in a linear image; with the
-// skew every 8th row shifts by 4 banks and the worst cases drop to 2- and 4-way
-// (SQ_LDS_BANK_CONFLICT, profiles/r01_lds_conflicts.md).
-__device__ __forceinline__ uint32_t lds_skew(uint32_t byte_off)
-    {
-    return byte_off + ((byte_off >> 7) << 4);
-    }
-
-// source tiles are read once and chunk tiles written once: non-temporal on both sides.  (Round 1 swept
-// LDS-DMA staging, default cache policies and a linear LDS image as compile-time variants: none was better,
-// profiles/r01_pack_sweep.jsonl; the variants were removed in round 2.)
-__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
-    {
-    return __builtin_nontemporal_load(p);
-    }
-
-__device__ __forceinline__ void stream_store(u32x4 v, u32x4* p)
-    {
-    __builtin_nontemporal_store(v, p);
-    }
-
 // Stream the re-packed tile of one output chunk from LDS to global memory:
 // 16 bytes per lane per store, lanes consecutive => each wave store covers 1 KiB.
 template<int SSZ, int DSZ, int NT, int KIND = -1>
@@ -468,109 +358,6 @@ template<int MODE> __global__ __launch_bounds__(PACK_THREADS) void pack_tiles_pr
 // stage -> barrier -> emit phases cost more than the odd store widths.
 // Workgroups are dealt to source arrays group-major (all workgroups of array 0, then array 1 ...):
 // a wave keeps one input and at most a few output streams open.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-// rows of 12 or 24 bytes are only dword / 8-byte aligned
-typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
-typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
-typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
-
-// a source row in registers: two SSA vectors (a C array indexed by a run-time column would be
-// demoted to scratch memory by the compiler)
-struct RowRegs
-    {
-    u32x4 lo, hi;
-    };
-
-template<int RW> __device__ __forceinline__ void row_load(const uint32_t* p, RowRegs& r)
-    {
-    if constexpr (RW == 1)
-        r.lo.x = __builtin_nontemporal_load(p);
-    else if constexpr (RW == 2)
-        {
-        u32x2 v = __builtin_nontemporal_load((const u32x2_a4*)p);
-        r.lo.x = v.x, r.lo.y = v.y;
-        }
-    else if constexpr (RW == 3)
-        {
-        u32x3 v = __builtin_nontemporal_load((const u32x3_a4*)p);
-        r.lo.x = v.x, r.lo.y = v.y, r.lo.z = v.z;
-        }
-    else
-        {
-        r.lo = __builtin_nontemporal_load((const u32x4_a4*)p);
-        if constexpr (RW == 6)
-            {
-            u32x2 w = __builtin_nontemporal_load((const u32x2_a4*)(p + 4));
-            r.hi.x = w.x, r.hi.y = w.y;
-            }
-        else if constexpr (RW == 8)
-            r.hi = __builtin_nontemporal_load((const u32x4_a4*)(p + 4));
-        }
-    }
-
-// dword `i` (wave-uniform) of a row held in registers
-template<int RW> __device__ __forceinline__ uint32_t row_pick(const RowRegs& r, uint32_t i)
-    {
-    if constexpr (RW == 1)
-        return r.lo.x;
-    else if constexpr (RW == 2)
-        return (i & 1u) ? r.lo.y : r.lo.x;
-    else if constexpr (RW <= 4)
-        {
-        const uint32_t a = (i & 1u) ? r.lo.y : r.lo.x, b = (i & 1u) ? r.lo.w : r.lo.z;
-        return (i & 2u) ? b : a;
-        }
-    else
-        {
-        const uint32_t a = (i & 1u) ? r.lo.y : r.lo.x, b = (i & 1u) ? r.lo.w : r.lo.z;
-        const uint32_t c = (i & 1u) ? r.hi.y : r.hi.x, d = (i & 1u) ? r.hi.w : r.hi.z;
-        const uint32_t ab = (i & 2u) ? b : a, cd = (i & 2u) ? d : c;
-        return (i & 4u) ? cd : ab;
-        }
-    }
-
-// nw (1..8, wave-uniform) dwords to row `i` of a chunk whose rows are nw dwords long
-template<uint32_t NWMAX>
-__device__ __forceinline__ void row_store(uint32_t* p, const uint32_t (&w)[ROWS_MAX_WORDS], uint32_t nw)
-    {
-    if (NWMAX >= 4 && nw >= 4)
-        {
-        u32x4 v = {w[0], w[1], w[2], w[3]};
-        __builtin_nontemporal_store(v, (u32x4_a4*)p);
-        if (NWMAX == 4)
-            return;
-        if (nw == 8)
-            {
-            u32x4 q = {w[4], w[5], w[6], w[7]};
-            __builtin_nontemporal_store(q, (u32x4_a4*)(p + 4));
-            }
-        else if (nw == 6)
-            {
-            u32x2 q = {w[4], w[5]};
-            __builtin_nontemporal_store(q, (u32x2_a4*)(p + 4));
-            }
-        else if (nw == 5)
-            __builtin_nontemporal_store(w[4], p + 4);
-        else if (nw == 7)
-            {
-            u32x3 q = {w[4], w[5], w[6]};
-            __builtin_nontemporal_store(q, (u32x3_a4*)(p + 4));
-            }
-        }
-    else if (nw == 3)
-        {
-        u32x3 v = {w[0], w[1], w[2]};
-        __builtin_nontemporal_store(v, (u32x3_a4*)p);
-        }
-    else if (nw == 2)
-        {
-        u32x2 v = {w[0], w[1]};
-        __builtin_nontemporal_store(v, (u32x2_a4*)p);
-        }
-    else
-        __builtin_nontemporal_store(w[0], p);
-    }
 
 // BITS_ONLY: every chunk of the launch moves dwords unchanged (the common case: float4 -> N x 3
 // floats, the type id in position.w, int3 images); no conversion code is generated
@@ -717,749 +504,9 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_generic_kernel(const PackGe
         }
     }
 
-// ------------------------------------------------------------------ unpack (read path)
-// Inverse of the pack.  The dense tiles of ALL chunks of a launch (contiguous bytes) are
-// streamed into LDS with 16-byte non-temporal loads, one barrier, then
-//   * destination arrays whose rows are completely restored by this launch (position.xyz and
-//     the type id into a Scalar4 array, velocity.xyz and mass, double4 builds ...) are
-//     assembled row-wise in registers and written with 16-byte non-temporal stores: whole
-//     lines, no partial-line writes;
-//   * every other chunk is scattered element-wise: lane e converts element e of the tile and
-//     stores it to its (row, column); columns no chunk restores are left untouched.
-// W32 = every chunk and destination element is 4 bytes wide and moved unchanged.
-template<bool W32> __device__ __forceinline__ uint64_t unpack_elem(const char* p, uint32_t ssz, uint32_t dsz, uint32_t kind)
-    {
-    if constexpr (W32)
-        return *(const uint32_t*)p;
-    else
-        {
-        switch (ssz)
-            {
-            case 1: return dsz == 8 ? convert_elem<1, 8>(lds_load<1>(p), kind) : convert_elem<1, 4>(lds_load<1>(p), kind);
-            case 2: return dsz == 8 ? convert_elem<2, 8>(lds_load<2>(p), kind) : convert_elem<2, 4>(lds_load<2>(p), kind);
-            case 4: return dsz == 8 ? convert_elem<4, 8>(lds_load<4>(p), kind) : convert_elem<4, 4>(lds_load<4>(p), kind);
-            default: return dsz == 4 ? convert_elem<8, 4>(lds_load<8>(p), kind) : convert_elem<8, 8>(lds_load<8>(p), kind);
-            }
-        }
-    }
-
-template<bool W32>
-__device__ __forceinline__ void scatter_tile(const UnpackJob& j, const char* lds, uint32_t rows, uint64_t row0)
-    {
-    const uint32_t M = j.M, ssz = W32 ? 4u : j.ssz, dsz = W32 ? 4u : j.dsz;
-    const uint32_t nelem = rows * M;
-    for (uint32_t e = threadIdx.x; e < nelem; e += PACK_THREADS)
-        {
-        uint32_t row = (M == 1) ? e : __umulhi(e, j.magic);
-        uint32_t col = e - row * M;
-        uint64_t val = unpack_elem<W32>(lds + (size_t)e * ssz, ssz, dsz, j.kind);
-        uint64_t drow = j.order ? (uint64_t)j.order[row0 + row] : row0 + row;
-        char* p = (char*)j.dst + (drow * j.dst_stride + j.dst_col0 + col) * dsz;
-        if (dsz == 8)
-            *(uint64_t*)p = val;
-        else if (dsz == 4)
-            *(uint32_t*)p = (uint32_t)val;
-        else if (dsz == 2)
-            *(uint16_t*)p = (uint16_t)val;
-        else
-            *(uint8_t*)p = (uint8_t)val;
-        }
-    }
-
-// Where one column of an assembled destination row comes from (kept in LDS: lanes that build
-// different vectors of a wide row look up different columns).
-struct UnpackCol
-    {
-    uint32_t base; // LDS byte offset of column 0 .. of row 0 of the chunk tile
-    uint32_t step; // bytes per chunk row
-    uint32_t ssz, kind;
-    };
-#define UNPACK_TABLE_BYTES (UNPACK_MAX_GROUPS * UNPACK_MAX_ROW_COLS * 16)
-
-// one 16-byte vector of a destination row per lane per step; rows are 16, 32 or 64 bytes
-template<bool W32>
-__device__ __forceinline__ void assemble_rows(const UnpackGroup& g, const UnpackCol* tab, const char* lds, uint32_t rows,
-                                              uint64_t row0)
-    {
-    const uint32_t shift = g.vec_shift, mask = (1u << shift) - 1u;
-    const uint32_t dsz = W32 ? 4u : g.dsz;
-    const uint32_t ept = 16u / dsz; // 4 or 2 elements per vector
-    const uint32_t nvec = rows << shift;
-    const uint32_t rowbytes = g.stride * dsz;
-    const uint32_t* order = g.order;
-    char* dst = (char*)g.dst;
-    if (shift == 0)
-        {
-        // 16-byte rows (Scalar4 of floats / ints): the four column descriptors are loop invariants
-        UnpackCol d[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-            d[k] = tab[k < ept ? k : 0];
-        for (uint32_t row = threadIdx.x; row < rows; row += PACK_THREADS)
-            {
-            uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++)
-                {
-                if (k >= ept)
-                    break;
-                uint64_t val = unpack_elem<W32>(lds + d[k].base + row * d[k].step, d[k].ssz, dsz, d[k].kind);
-                if (dsz == 8)
-                    {
-                    w[2 * k] = (uint32_t)val;
-                    w[2 * k + 1] = (uint32_t)(val >> 32);
-                    }
-                else
-                    w[k] = (uint32_t)val;
-                }
-            const uint64_t drow = order ? (uint64_t)order[row0 + row] : row0 + row;
-            u32x4 out = {w[0], w[1], w[2], w[3]};
-            __builtin_nontemporal_store(out, (u32x4*)(dst + drow * 16));
-            }
-        return;
-        }
-    for (uint32_t v = threadIdx.x; v < nvec; v += PACK_THREADS)
-        {
-        const uint32_t row = v >> shift, q = v & mask;
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-            {
-            if (k >= ept)
-                break;
-            const UnpackCol d = tab[q * ept + k];
-            uint64_t val = unpack_elem<W32>(lds + d.base + row * d.step, d.ssz, dsz, d.kind);
-            if (dsz == 8)
-                {
-                w[2 * k] = (uint32_t)val;
-                w[2 * k + 1] = (uint32_t)(val >> 32);
-                }
-            else
-                w[k] = (uint32_t)val;
-            }
-        const uint64_t drow = order ? (uint64_t)order[row0 + row] : row0 + row;
-        u32x4 out = {w[0], w[1], w[2], w[3]};
-        __builtin_nontemporal_store(out, (u32x4*)(dst + drow * rowbytes + (size_t)q * 16));
-        }
-    }
-
-template<bool W32> __global__ __launch_bounds__(PACK_THREADS) void unpack_tiles_kernel(const UnpackArgs args)
-    {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t TILE = args.tile_rows;
-    // column table of the assembled arrays, once per workgroup (chunk tiles start behind it)
-    UnpackCol* tab = (UnpackCol*)lds;
-    if (tid < args.n_groups * UNPACK_MAX_ROW_COLS)
-        {
-        const UnpackGroup& g = args.g[tid / UNPACK_MAX_ROW_COLS];
-        const uint32_t col = tid % UNPACK_MAX_ROW_COLS;
-        UnpackCol d = {0, 0, 4, 0};
-        if (col < g.stride)
-            {
-            const UnpackJob& j = args.j[g.col_job[col]];
-            d.base = j.lds_off + g.col_off[col] * j.ssz;
-            d.step = j.rowbytes;
-            d.ssz = j.ssz;
-            d.kind = j.kind;
-            }
-        tab[tid] = d;
-        }
-    // (the first tile's barrier publishes the table)
-    for (uint64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x)
-        {
-        const uint64_t row0 = tile * TILE;
-        const uint32_t rows = (uint32_t)((args.N - row0 < (uint64_t)TILE) ? args.N - row0 : TILE);
-        // every chunk tile in flight before the first byte is consumed
-        for (uint32_t ji = 0; ji < args.n_jobs; ji++)
-            {
-            const UnpackJob& j = args.j[ji];
-            const char* gsrc = (const char*)j.src + row0 * j.rowbytes;
-            char* l = lds + j.lds_off;
-            const uint32_t nbytes = rows * j.rowbytes;
-            const uint32_t nvec = nbytes >> 4;
-            uint32_t v = tid;
-            for (; v + 3 * PACK_THREADS < nvec; v += 4 * PACK_THREADS)
-                {
-                u32x4 a = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-                u32x4 b = __builtin_nontemporal_load((const u32x4*)gsrc + v + PACK_THREADS);
-                u32x4 c = __builtin_nontemporal_load((const u32x4*)gsrc + v + 2 * PACK_THREADS);
-                u32x4 d = __builtin_nontemporal_load((const u32x4*)gsrc + v + 3 * PACK_THREADS);
-                ((u32x4*)l)[v] = a;
-                ((u32x4*)l)[v + PACK_THREADS] = b;
-                ((u32x4*)l)[v + 2 * PACK_THREADS] = c;
-                ((u32x4*)l)[v + 3 * PACK_THREADS] = d;
-                }
-            for (; v < nvec; v += PACK_THREADS)
-                ((u32x4*)l)[v] = __builtin_nontemporal_load((const u32x4*)gsrc + v);
-            for (uint32_t b = (nvec << 4) + tid; b < nbytes; b += PACK_THREADS)
-                l[b] = gsrc[b];
-            }
-        __syncthreads();
-        for (uint32_t gi = 0; gi < args.n_groups; gi++)
-            assemble_rows<W32>(args.g[gi], tab + gi * UNPACK_MAX_ROW_COLS, lds, rows, row0);
-        for (uint32_t ji = 0; ji < args.n_jobs; ji++)
-            if (!args.j[ji].in_group)
-                scatter_tile<W32>(args.j[ji], lds + args.j[ji].lds_off, rows, row0);
-        __syncthreads();
-        }
-    }
-
-// ------------------------------------------------------------------ row-per-lane unpack (Scalar4 destinations)
-// Inverse of pack_rows_kernel for the restart path's common shape: a float4-like destination array fed by
-// one or two dense chunks (position.xyz + the type id into position.w, velocity.xyz + mass).  Lane i loads
-// row i of each chunk (12 bytes + 4 bytes: contiguous pieces, consecutive lanes consecutive rows), and
-// stores ONE 16-byte row (two for a double4 destination restored from f32 chunks).  No LDS, no barrier;
-// blockIdx.y = destination array; dense same-type arrays ride along as 16-byte copies.  Measured in the lab
-// (the round-2 lab, profiles/r02_lab_unpack.jsonl): 100 us for position + id + velocity + mass of 10 M
-// particles where the LDS-tiled unpack needs 113 us.  A first, fully generic version of this kernel (run-time
-// chunk lists and widths) was no faster than the tiled one; the static hot path is what pays.
-template<bool F64> __device__ __forceinline__ void unrows_store(uint32_t* drow, const uint32_t* w, uint32_t nw, uint32_t col0)
-    {
-    // nw source dwords (f32 / 32-bit integers) -> destination elements col0 .. col0+nw
-    if constexpr (!F64)
-        {
-        uint32_t c[ROWS_MAX_WORDS] = {w[0], w[1], w[2], w[3], 0, 0, 0, 0};
-        row_store<4>(drow + col0, c, nw);
-        }
-    else
-        {
-        uint32_t c[ROWS_MAX_WORDS];
-#pragma unroll
-        for (uint32_t e = 0; e < 4; e++)
-            {
-            const uint64_t bits = (uint64_t)__double_as_longlong((double)__uint_as_float(w[e]));
-            c[2 * e] = (uint32_t)bits;
-            c[2 * e + 1] = (uint32_t)(bits >> 32);
-            }
-        row_store<8>(drow + 2 * col0, c, 2 * nw);
-        }
-    }
-
-__device__ __forceinline__ void unrows_load(const uint32_t* p, uint32_t nw, uint32_t (&w)[4])
-    {
-    RowRegs r;
-    r.lo = u32x4 {0, 0, 0, 0};
-    switch (nw)
-        {
-        case 1: row_load<1>(p, r); break;
-        case 2: row_load<2>(p, r); break;
-        case 3: row_load<3>(p, r); break;
-        default: row_load<4>(p, r); break;
-        }
-    w[0] = r.lo.x, w[1] = r.lo.y, w[2] = r.lo.z, w[3] = r.lo.w;
-    }
-
-// One WHOLE destination row: column e takes v[e] (f32 / 32-bit bits from a chunk) unless bit e of fillmask is
-// set, then the fill element.  Compile-time loops only (a run-time index into c[] would go to scratch).
-template<bool F64>
-__device__ __forceinline__ void unrows_store_whole(uint32_t* drow, const uint32_t (&v)[4], uint32_t fillmask, uint32_t fill_lo,
-                                                   uint32_t fill_hi)
-    {
-    if constexpr (!F64)
-        {
-        uint32_t c[ROWS_MAX_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (uint32_t e = 0; e < 4; e++)
-            c[e] = ((fillmask >> e) & 1u) ? fill_lo : v[e];
-        row_store<4>(drow, c, 4);
-        }
-    else
-        {
-        uint32_t c[ROWS_MAX_WORDS];
-#pragma unroll
-        for (uint32_t e = 0; e < 4; e++)
-            {
-            const uint64_t bits = (uint64_t)__double_as_longlong((double)__uint_as_float(v[e]));
-            const bool f = (fillmask >> e) & 1u;
-            c[2 * e] = f ? fill_lo : (uint32_t)bits;
-            c[2 * e + 1] = f ? fill_hi : (uint32_t)(bits >> 32);
-            }
-        row_store<8>(drow, c, 8);
-        }
-    }
-
-// v[col0 + s] = w[s] for s < nw, without run-time indexing
-__device__ __forceinline__ void unrows_place(uint32_t (&v)[4], const uint32_t (&w)[4], uint32_t nw, uint32_t col0)
-    {
-#pragma unroll
-    for (uint32_t e = 0; e < 4; e++)
-#pragma unroll
-        for (uint32_t s = 0; s < 4; s++)
-            if (s < nw && col0 + s == e)
-                v[e] = w[s];
-    }
-
-template<int T, int U, bool F64> __global__ __launch_bounds__(T) void unpack_rows_kernel(const UnrowsArgs args)
-    {
-    const UnrowsGroup& g = args.g[blockIdx.y];
-    if (g.copy_vecs != 0 || g.copy_tail != 0)
-        {
-        // dense same-type array: the chunk IS the array
-        const u32x4* src = (const u32x4*)g.a;
-        u32x4* dst = (u32x4*)g.dst;
-        const uint64_t nvec = g.copy_vecs;
-        const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
-        const uint64_t first = (uint64_t)blockIdx.x * per;
-        const uint64_t last = first + per < nvec ? first + per : nvec;
-        for (uint64_t v = first + threadIdx.x; v < last; v += T)
-            __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
-        if (blockIdx.x == 0 && threadIdx.x < g.copy_tail)
-            ((char*)dst)[nvec * 16 + threadIdx.x] = ((const char*)src)[nvec * 16 + threadIdx.x];
-        return;
-        }
-    const uint64_t N = args.N;
-    const uint64_t base = (uint64_t)blockIdx.x * (uint64_t)(T * U) + threadIdx.x;
-    constexpr uint32_t DW = F64 ? 8 : 4;
-    uint32_t* dst = (uint32_t*)g.dst;
-    const uint32_t* a = (const uint32_t*)g.a;
-    const uint32_t* b = (const uint32_t*)g.b;
-    if (g.a_nw == 3 && g.a_col0 == 0 && b == nullptr && g.fill_on)
-        {
-        // xyz from a chunk, w = a constant (velocity without a mass chunk -> {vx, vy, vz, 1.0f}): whole rows out
-        u32x3 xyz[U];
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * T;
-            if (i < N)
-                xyz[k] = __builtin_nontemporal_load((const u32x3_a4*)(a + i * 3));
-            }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * T;
-            if (i < N)
-                {
-                const uint32_t c[4] = {xyz[k].x, xyz[k].y, xyz[k].z, 0};
-                unrows_store_whole<F64>(dst + i * DW, c, 8u, g.fill_lo, g.fill_hi);
-                }
-            }
-        return;
-        }
-    if (g.fill_on)
-        {
-        // any other one- or two-chunk shape with a fill: compose the whole row, one store
-        uint32_t mask = 15u;
-#pragma unroll
-        for (uint32_t s = 0; s < 4; s++)
-            {
-            if (s < g.a_nw)
-                mask &= ~(1u << (g.a_col0 + s));
-            if (b != nullptr && s < g.b_nw)
-                mask &= ~(1u << (g.b_col0 + s));
-            }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * T;
-            if (i >= N)
-                continue;
-            uint32_t wa[4], wb[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
-            unrows_load(a + i * g.a_nw, g.a_nw, wa);
-            unrows_place(v, wa, g.a_nw, g.a_col0);
-            if (b != nullptr)
-                {
-                unrows_load(b + i * g.b_nw, g.b_nw, wb);
-                unrows_place(v, wb, g.b_nw, g.b_col0);
-                }
-            unrows_store_whole<F64>(dst + i * DW, v, mask, g.fill_lo, g.fill_hi);
-            }
-        return;
-        }
-    if (g.a_nw == 3 && g.a_col0 == 0 && b != nullptr && g.b_nw == 1 && g.b_col0 == 3)
-        {
-        // the hot shape: xyz from one chunk, w from another, whole rows out
-        u32x3 xyz[U];
-        uint32_t w[U];
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * T;
-            if (i < N)
-                {
-                xyz[k] = __builtin_nontemporal_load((const u32x3_a4*)(a + i * 3));
-                w[k] = __builtin_nontemporal_load(b + i);
-                }
-            }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * T;
-            if (i < N)
-                {
-                const uint32_t c[4] = {xyz[k].x, xyz[k].y, xyz[k].z, w[k]};
-                unrows_store<F64>(dst + i * DW, c, 4, 0);
-                }
-            }
-        return;
-        }
-    // any other one- or two-chunk shape: each chunk's elements go to their columns
-#pragma unroll
-    for (int k = 0; k < U; k++)
-        {
-        const uint64_t i = base + (uint64_t)k * T;
-        if (i >= N)
-            continue;
-        uint32_t wa[4], wb[4] = {0, 0, 0, 0};
-        unrows_load(a + i * g.a_nw, g.a_nw, wa);
-        if (b != nullptr)
-            unrows_load(b + i * g.b_nw, g.b_nw, wb);
-        unrows_store<F64>(dst + i * DW, wa, g.a_nw, g.a_col0);
-        if (b != nullptr)
-            unrows_store<F64>(dst + i * DW, wb, g.b_nw, g.b_col0);
-        }
-    }
-
-// ------------------------------------------------------------------ fill of untouched columns (generic paths)
-// pgsd_field_dst.fill_rest where the launch does not assemble whole rows (scatter index, narrow or wide
-// elements, more than two chunks per array): the columns in colmask of every destination row receive the fill
-// element before the chunks' kernels run.  Element per lane: a fallback, not a hot path.
-__global__ __launch_bounds__(256) void fill_cols_kernel(const FillArgs a)
-    {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t row = t / a.stride;
-    const uint32_t col = (uint32_t)(t % a.stride);
-    if (row >= a.N || col >= 32 || !((a.colmask >> col) & 1u))
-        return;
-    const uint64_t r = a.order ? (uint64_t)a.order[row] : row;
-    char* p = (char*)a.dst + (r * a.stride + col) * a.dsz;
-    switch (a.dsz)
-        {
-        case 1: *(uint8_t*)p = (uint8_t)a.bits; break;
-        case 2: *(uint16_t*)p = (uint16_t)a.bits; break;
-        case 4: *(uint32_t*)p = (uint32_t)a.bits; break;
-        default: *(uint64_t*)p = a.bits; break;
-        }
-    }
-
-// ------------------------------------------------------------------ packed chunk == reference rows ?
-// pgsd.hoomd elides a per-particle array that equals frame 0's, or the schema's default where frame 0 has no such chunk
-// (hoomd.py:654-694: numpy.array_equal / a broadcast comparison).  For arrays that live in HBM the test runs here: the
-// chunk is packed as usual, then its packed bytes are compared with the reference rows (also in device memory) -- 16
-// bytes per lane and load, four loads of each side in flight, grid-stride.  Bandwidth-bound when the arrays are equal
-// (2 x chunk bytes read -- 1 x against a short REPEATING reference, which stays in the L2 --, nothing written).
-// Equality is numpy's: integer chunks by their bytes, float chunks by VALUE -- a NaN differs from everything, itself
-// included, +0.0 equals -0.0 -- decided on the bit patterns (no floating-point instruction, so no denormal mode can
-// come into it).  Arrays that differ differ early, so a PROBE launch -- four workgroups per job over its first 64
-// KiB -- runs first: the full launch's workgroups of a job the probe marked leave at once (had they all found the
-// difference themselves, thousands of waves would each have sent their mark across PCIe: 237 us for two moving arrays
-// of 10 M rows against 129 us for six equal ones).  A difference further in is still found by the full launch; the
-// first workgroup to see it marks the job and the others stop at their next stride.  The flag words are never
-// cleared: a launch marks with its own generation number.
-// The common case is "equal": the test is shaped for it.  Per 16-byte vector: OR of the XORs (any bit differs?) and, for
-// float chunks, the largest |x| bit pattern of the CHUNK's words shifted left by one (sign out): above 0xff000000 it
-// is a NaN, which equals nothing -- itself included.  Only when bits differ does the slow look decide whether it is
-// a +0.0 / -0.0 pair (equal by value) -- a path an equal array never takes and a different one leaves the kernel on.
-template <int MODE> __device__ __forceinline__ uint32_t cmp_differ16(const u32x4 x, const u32x4 y)
-    {
-    const uint32_t differ = (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
-    if (MODE == CMP_BYTES)
-        return differ;
-    if (MODE == CMP_F32)
-        {
-        const uint32_t m = max(max(x.x << 1, x.y << 1), max(x.z << 1, x.w << 1));
-        uint32_t bad = m > 0xff000000u ? 1u : 0u; // a NaN among the chunk's four floats
-        if (differ != 0)
-            {
-            const uint32_t a[4] = {x.x, x.y, x.z, x.w}, b[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) // bits differ: equal all the same when both are zeros of either sign
-                bad |= ((a[k] ^ b[k]) != 0 && ((a[k] | b[k]) << 1) != 0) ? 1u : 0u;
-            }
-        return bad;
-        }
-    // CMP_F64: two doubles per vector, little endian (low word first).  (hi << 1) | (lo != 0) > 0xffe00000: a NaN
-    const uint32_t t0 = (x.y << 1) | (x.x != 0 ? 1u : 0u), t1 = (x.w << 1) | (x.z != 0 ? 1u : 0u);
-    uint32_t bad = max(t0, t1) > 0xffe00000u ? 1u : 0u;
-    if (differ != 0)
-        {
-        const uint32_t al[2] = {x.x, x.z}, ah[2] = {x.y, x.w}, bl[2] = {y.x, y.z}, bh[2] = {y.y, y.w};
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            bad |= (((al[k] ^ bl[k]) | (ah[k] ^ bh[k])) != 0 && (((ah[k] | bh[k]) << 1) | al[k] | bl[k]) != 0) ? 1u : 0u;
-        }
-    return bad;
-    }
-
-// one element of `es` bytes (1: a byte of an integer chunk) at byte offset `at`, assembled from bytes: the slow road of
-// unaligned pointers and of the last bytes
-__device__ __forceinline__ bool cmp_differ_element(const char* pa, const char* pb, uint64_t at, uint64_t at_b, uint32_t es,
-                                                   uint32_t mode)
-    {
-    uint64_t a = 0, b = 0;
-    for (uint32_t k = 0; k < es; k++)
-        {
-        a |= (uint64_t)(uint8_t)pa[at + k] << (8 * k);
-        b |= (uint64_t)(uint8_t)pb[at_b + k] << (8 * k);
-        }
-    if (mode == CMP_F32)
-        return ((a ^ b) != 0 && ((a | b) & 0x7fffffffull) != 0) || (a & 0x7fffffffull) > 0x7f800000ull;
-    if (mode == CMP_F64)
-        return ((a ^ b) != 0 && ((a | b) & 0x7fffffffffffffffull) != 0) || (a & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
-    return a != b;
-    }
-
-template <int MODE, bool PERIODIC>
-__device__ __forceinline__ bool cmp_vector_loop(const u32x4* a, const u32x4* b, uint64_t n16, uint64_t period16, const uint32_t* df,
-                                                uint32_t gen)
-    {
-    const uint64_t per_block = 256 * 4;
-    for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n16; base += (uint64_t)gridDim.x * per_block)
-        {
-        if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
-            return false; // somebody else has the answer
-        // a repeating reference: ONE modulo per lane and stride, the three further vectors by a conditional step back
-        // (period16 >= 256 is checked by the host)
-        uint64_t bi = PERIODIC ? (base + threadIdx.x) % period16 : 0;
-        u32x4 x[4], y[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            {
-            const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-            x[k] = (u32x4)(0u);
-            y[k] = (u32x4)(0u);
-            if (i < n16)
-                {
-                x[k] = __builtin_nontemporal_load(a + i);
-                y[k] = PERIODIC ? b[bi] : __builtin_nontemporal_load(b + i);
-                }
-            if (PERIODIC)
-                {
-                bi += 256;
-                if (bi >= period16)
-                    bi -= period16;
-                }
-            }
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            acc |= cmp_differ16<MODE>(x[k], y[k]);
-        if (acc != 0)
-            return true;
-        }
-    return false;
-    }
-
-__global__ __launch_bounds__(256) void compare_bytes_kernel(const CompareArgs args)
-    {
-    CompareJob jb = args.j[blockIdx.y];
-    uint32_t* df = args.dflags + blockIdx.y;
-    if (args.limit != 0 && jb.bytes > args.limit)
-        jb.bytes = args.limit;
-    if (__hip_atomic_load(df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == args.gen)
-        return; // marked by the probe (or by a quicker workgroup)
-    bool diff = false;
-    const char* pa = (const char*)jb.a;
-    const char* pb = (const char*)jb.b;
-    uint64_t done = 0; // bytes covered by the vector loop
-    if ((((uintptr_t)pa | (uintptr_t)pb) & 15) == 0)
-        {
-        const u32x4* a = (const u32x4*)pa;
-        const u32x4* b = (const u32x4*)pb;
-        const uint64_t n16 = jb.bytes >> 4;
-        const uint64_t p16 = jb.period >> 4;
-        done = n16 << 4;
-        if (jb.period == 0)
-            diff = jb.mode == CMP_F32   ? cmp_vector_loop<CMP_F32, false>(a, b, n16, 0, df, args.gen)
-                   : jb.mode == CMP_F64 ? cmp_vector_loop<CMP_F64, false>(a, b, n16, 0, df, args.gen)
-                                        : cmp_vector_loop<CMP_BYTES, false>(a, b, n16, 0, df, args.gen);
-        else
-            diff = jb.mode == CMP_F32   ? cmp_vector_loop<CMP_F32, true>(a, b, n16, p16, df, args.gen)
-                   : jb.mode == CMP_F64 ? cmp_vector_loop<CMP_F64, true>(a, b, n16, p16, df, args.gen)
-                                        : cmp_vector_loop<CMP_BYTES, true>(a, b, n16, p16, df, args.gen);
-        }
-    // what the vector loop left: the last bytes, or everything when a side is not 16-byte aligned -- element by element
-    const uint32_t es = jb.mode == CMP_F32 ? 4u : jb.mode == CMP_F64 ? 8u : 1u;
-    for (uint64_t i = done + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * es; i + es <= jb.bytes && !diff;
-         i += (uint64_t)gridDim.x * 256 * es)
-        diff = cmp_differ_element(pa, pb, i, jb.period ? i % jb.period : i, es, jb.mode);
-    const uint64_t who = __ballot(diff);
-    if (who != 0 && (uint32_t)(__ffsll((unsigned long long)who) - 1) == (threadIdx.x & 63u))
-        {
-        __hip_atomic_store(df, args.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(args.hflags + blockIdx.y, args.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-
-int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32_t* dflags, uint32_t* hflags,
-                   hipStream_t stream, std::string* err)
-    {
-    if (n_jobs == 0)
-        return PGSD_SUCCESS;
-    if (n_jobs > CMP_MAX_JOBS || !jobs || !dflags || !hflags)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    CompareArgs args;
-    memset(&args, 0, sizeof(args));
-    args.dflags = dflags;
-    args.hflags = hflags;
-    args.gen = gen;
-    args.n_jobs = n_jobs;
-    uint64_t most = 0;
-    for (uint32_t i = 0; i < n_jobs; i++)
-        {
-        args.j[i] = jobs[i];
-        most = std::max<uint64_t>(most, jobs[i].bytes);
-        }
-    // one workgroup per 16 KiB of the longest job, at most eight per CU of the part (2048): grid-stride beyond
-    uint64_t blocks = (most + 16383) / 16384;
-    blocks = std::min<uint64_t>(std::max<uint64_t>(blocks, 1), 2048);
-    if (most > 65536)
-        {
-        args.limit = 65536;
-        hipLaunchKernelGGL(compare_bytes_kernel, dim3(4, n_jobs), dim3(256), 0, stream, args); // 16 KiB per workgroup
-        args.limit = 0;
-        }
-    hipLaunchKernelGGL(compare_bytes_kernel, dim3((unsigned)blocks, n_jobs), dim3(256), 0, stream, args);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        {
-        if (err)
-            *err = std::string("compare kernel launch failed: ") + hipGetErrorString(e);
-        return PGSD_ERROR_DEVICE;
-        }
-    return PGSD_SUCCESS;
-    }
-
-// ------------------------------------------------------------------ select (compaction)
-#define SEL_THREADS 256
-#define SEL_PER_THREAD 16
-#define SEL_PER_BLOCK (SEL_THREADS * SEL_PER_THREAD)
-
-// number of non-zero flag bytes among the 16 this lane owns
-__device__ __forceinline__ uint32_t sel_load16(const uint8_t* flags, uint64_t base, uint64_t N, uint32_t* mask)
-    {
-    uint32_t m = 0;
-    if (base + SEL_PER_THREAD <= N && ((uintptr_t)(flags + base) & 15) == 0)
-        {
-        u32x4 v = *(const u32x4*)(flags + base);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            m |= (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) != 0 ? 1u : 0u) << k;
-        }
-    else
-        {
-        for (int k = 0; k < 16; k++)
-            if (base + k < N && flags[base + k] != 0)
-                m |= 1u << k;
-        }
-    *mask = m;
-    return (uint32_t)__popc(m);
-    }
-
-// inclusive scan of one value per lane across the 64-lane wavefront
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
-    {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-        {
-        uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d)
-            x += y;
-        }
-    return x;
-    }
-
-__global__ __launch_bounds__(SEL_THREADS) void select_count_kernel(const uint8_t* flags, uint64_t N,
-                                                                   uint32_t* block_counts)
-    {
-    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
-    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
-    uint32_t mask;
-    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
-    uint32_t inc = wave_inclusive_scan(c);
-    if ((threadIdx.x & 63) == 63)
-        wave_sums[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        block_counts[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
-    }
-
-// exclusive scan of the block counts by ONE workgroup; also writes the total
-__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
-                                                                  uint64_t* block_offsets,
-                                                                  uint64_t* out_count)
-    {
-    __shared__ uint64_t carry;
-    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
-    if (threadIdx.x == 0)
-        carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += SEL_THREADS)
-        {
-        uint32_t i = b0 + threadIdx.x;
-        uint32_t c = i < n_blocks ? block_counts[i] : 0;
-        uint32_t inc = wave_inclusive_scan(c);
-        if ((threadIdx.x & 63) == 63)
-            wave_sums[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-            wave_off += wave_sums[w];
-        if (i < n_blocks)
-            block_offsets[i] = carry + wave_off + inc - c;
-        __syncthreads();
-        if (threadIdx.x == SEL_THREADS - 1)
-            carry += (uint64_t)wave_off + inc;
-        __syncthreads();
-        }
-    if (threadIdx.x == 0)
-        *out_count = carry;
-    }
-
-__global__ __launch_bounds__(SEL_THREADS) void select_scatter_kernel(const uint8_t* flags, uint64_t N,
-                                                                     const uint64_t* block_offsets,
-                                                                     uint32_t* out_index)
-    {
-    // The kept rows of this block are compacted in LDS first (each lane drops its <= 16 indices at
-    // its block-local rank), then the block writes them out as one dense, coalesced run: lane i
-    // stores element i of the run instead of 16 scattered stores per lane.
-    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
-    __shared__ uint32_t local[SEL_PER_BLOCK];
-    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
-    uint32_t mask = 0;
-    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
-    uint32_t inc = wave_inclusive_scan(c);
-    if ((threadIdx.x & 63) == 63)
-        wave_sums[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t wave_off = 0, total = 0;
-    for (uint32_t w = 0; w < SEL_THREADS / 64; w++)
-        {
-        if (w < (threadIdx.x >> 6))
-            wave_off += wave_sums[w];
-        total += wave_sums[w];
-        }
-    uint32_t pos = wave_off + inc - c;
-    while (mask)
-        {
-        int k = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        local[pos++] = (uint32_t)(base + (uint64_t)k);
-        }
-    __syncthreads();
-    uint32_t* out = out_index + block_offsets[blockIdx.x];
-    // 16-byte stores where the run's start allows, 4-byte stores for the ragged ends
-    const uint32_t lead = (uint32_t)((4u - (((uintptr_t)out >> 2) & 3u)) & 3u);
-    const uint32_t head = lead < total ? lead : total;
-    if (threadIdx.x < head)
-        out[threadIdx.x] = local[threadIdx.x];
-    const uint32_t nvec = (total - head) >> 2;
-    for (uint32_t v = threadIdx.x; v < nvec; v += SEL_THREADS)
-        {
-        const uint32_t e = head + 4 * v;
-        u32x4 q = {local[e], local[e + 1], local[e + 2], local[e + 3]};
-        *(u32x4*)(out + e) = q;
-        }
-    for (uint32_t e = head + 4 * nvec + threadIdx.x; e < total; e += SEL_THREADS)
-        out[e] = local[e];
-    }
-
 // ------------------------------------------------------------------ host side
 
-static uint32_t conv_kind(uint32_t src_type, uint32_t dst_type, uint32_t bitcast)
+uint32_t conv_kind(uint32_t src_type, uint32_t dst_type, uint32_t bitcast)
     {
     const bool s_int = src_type <= PGSD_TYPE_INT64, d_int = dst_type <= PGSD_TYPE_INT64;
     const size_t ssz = sizeof_type(src_type), dsz = sizeof_type(dst_type);
@@ -1503,7 +550,7 @@ uint64_t pack_bytes_out(const pgsd_pack_job& j, uint64_t N)
 
 static int g_num_cus = 0;
 
-static int num_cus()
+int num_cus()
     {
     if (g_num_cus == 0)
         {
@@ -1518,6 +565,7 @@ static int num_cus()
     }
 
 // the LDS-tiled kernels: plain or software-pipelined, one instantiation per conversion class
+
 static void launch_tiles(bool prefetch, int mode, unsigned blocks, size_t lds_bytes, hipStream_t stream,
                          const PackArgs& args, hipEvent_t ev_start, hipEvent_t ev_stop)
     {
@@ -1547,23 +595,7 @@ static void launch_tiles(bool prefetch, int mode, unsigned blocks, size_t lds_by
 #undef TILES_LAUNCH
     }
 
-// ---- tuning knobs: the PGSD_PACK_* / PGSD_UNPACK_* variables of the sweeps in tools/ (pack_bench.py, unpack_bench.py).
-// Read ONCE, when the first launch needs them; pgsd_reload_tuning() (pgsd_private.h) reads them again for tools
-// that A/B variants inside one process.  Defaults come from measurements on MI355X (profiles/).
-struct PackTuning
-    {
-    int rows_t = 0, rows_u = 0;           // PGSD_PACK_ROWS_CFG "<threads>x<rows per lane>" (0: by size)
-    bool pack_tiles = false;              // PGSD_PACK_KERNEL=tiles: the LDS-tiled kernel for everything (A/B, tests)
-    uint64_t per_cu = 4;                  // PGSD_PACK_BLOCKS_PER_CU
-    uint32_t tile_cap = 1024;             // PGSD_PACK_TILE
-    size_t lds_budget = PACK_LDS_BYTES;   // PGSD_PACK_LDS_KB
-    int prefetch = -1;                    // PGSD_PACK_PREFETCH (-1: by size)
-    int unrows_t = 0, unrows_u = 0;       // PGSD_UNPACK_ROWS_CFG (0: the default 64x2)
-    uint32_t unpack_tile_cap = 0;         // PGSD_UNPACK_TILE (0: by size)
-    uint64_t unpack_per_cu = 8;           // PGSD_UNPACK_BLOCKS_PER_CU
-    bool unpack_tiles = false;            // PGSD_UNPACK_KERNEL=tiles
-    };
-
+// ---- tuning knobs (struct PackTuning: pgsd_kernels.hpp)
 static std::mutex g_tuning_lock;
 static bool g_tuning_loaded = false;
 static PackTuning g_tuning;
@@ -1612,7 +644,7 @@ static PackTuning read_tuning()
     return t;
     }
 
-static PackTuning tuning()
+PackTuning tuning()
     {
     std::lock_guard<std::mutex> guard(g_tuning_lock);
     if (!g_tuning_loaded)
@@ -2000,366 +1032,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         }
     return PGSD_SUCCESS;
     }
-// ---- row-per-lane unpack: which destination arrays it takes and how it is launched
-struct UnrowsPlan
-    {
-    UnrowsArgs args;
-    bool f64 = false;
-    };
-
-static void launch_unrows(const UnrowsPlan& p, uint64_t N, hipStream_t stream)
-    {
-    // measured (profiles/r02_lab_unpack.jsonl, r02_unpack_rows_final.jsonl): thin workgroups; 64 x 2 rows
-    // 102.4-103.0 us, 128 x 1 104.6-105.0 us, 256 x 2 105.9-106.0 us (10 M particles, stream events)
-    int T = 64, U = 2;
-    const PackTuning tune = tuning();
-    if (tune.unrows_t)
-        T = tune.unrows_t, U = tune.unrows_u;
-    UnrowsArgs a = p.args;
-    a.n_blocks = (N + (uint64_t)T * U - 1) / ((uint64_t)T * U);
-    const dim3 grid((unsigned)a.n_blocks, a.n_groups);
-#define UNROWS_LAUNCH(TT, UU)                                                                                  \
-    if (T == TT && U == UU)                                                                                    \
-        {                                                                                                      \
-        if (p.f64)                                                                                             \
-            hipLaunchKernelGGL((unpack_rows_kernel<TT, UU, true>), grid, dim3(TT), 0, stream, a);              \
-        else                                                                                                   \
-            hipLaunchKernelGGL((unpack_rows_kernel<TT, UU, false>), grid, dim3(TT), 0, stream, a);             \
-        return;                                                                                                \
-        }
-    UNROWS_LAUNCH(128, 1)
-    UNROWS_LAUNCH(256, 1)
-    UNROWS_LAUNCH(256, 2)
-    UNROWS_LAUNCH(128, 2)
-    a.n_blocks = (N + 127) / 128;
-    const dim3 grid1((unsigned)a.n_blocks, a.n_groups);
-    if (p.f64)
-        hipLaunchKernelGGL((unpack_rows_kernel<64, 2, true>), grid1, dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL((unpack_rows_kernel<64, 2, false>), grid1, dim3(64), 0, stream, a);
-#undef UNROWS_LAUNCH
-    }
-
-// One batch of <= UNPACK_MAX_JOBS validated chunks -> one launch.
-static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, hipStream_t stream)
-    {
-    UnpackArgs args;
-    memset(&args, 0, sizeof(args));
-    args.N = N;
-    args.n_jobs = (uint32_t)jobs.size();
-    uint32_t sum_rowbytes = 0;
-    bool w32 = true;
-    for (uint32_t i = 0; i < args.n_jobs; i++)
-        {
-        args.j[i] = jobs[i];
-        sum_rowbytes += jobs[i].rowbytes;
-        w32 = w32 && jobs[i].ssz == 4 && jobs[i].dsz == 4 && jobs[i].kind == PACK_BITS;
-        }
-    // destination arrays whose rows this batch restores completely: dst row of 16, 32 or 64 bytes,
-    // 4- or 8-byte elements, every column written by exactly one chunk
-    for (uint32_t i = 0; i < args.n_jobs && args.n_groups < UNPACK_MAX_GROUPS; i++)
-        {
-        UnpackJob& a = args.j[i];
-        if (a.in_group)
-            continue;
-        const uint32_t rowbytes = a.dst_stride * a.dsz;
-        if ((a.dsz != 4 && a.dsz != 8) || (rowbytes != 16 && rowbytes != 32 && rowbytes != 64)
-            || (((uintptr_t)a.dst) & 15) != 0)
-            continue;
-        UnpackGroup g;
-        memset(&g, 0, sizeof(g));
-        uint8_t covered[UNPACK_MAX_ROW_COLS] = {0};
-        uint32_t n_cov = 0;
-        bool clean = true;
-        for (uint32_t k = i; k < args.n_jobs; k++)
-            {
-            const UnpackJob& b = args.j[k];
-            if (b.dst != a.dst || b.in_group)
-                continue;
-            if (b.order != a.order || b.dst_stride != a.dst_stride || b.dsz != a.dsz)
-                {
-                clean = false; // same array seen through different shapes: leave it to the element path
-                break;
-                }
-            for (uint32_t c = 0; c < b.M; c++)
-                {
-                if (covered[b.dst_col0 + c])
-                    clean = false;
-                covered[b.dst_col0 + c] = 1;
-                g.col_job[b.dst_col0 + c] = (uint8_t)k;
-                g.col_off[b.dst_col0 + c] = (uint8_t)c;
-                n_cov++;
-                }
-            }
-        if (!clean || n_cov != a.dst_stride)
-            continue;
-        g.dst = a.dst;
-        g.order = a.order;
-        g.stride = a.dst_stride;
-        g.dsz = a.dsz;
-        g.vec_shift = rowbytes == 16 ? 0u : (rowbytes == 32 ? 1u : 2u);
-        for (uint32_t k = i; k < args.n_jobs; k++)
-            if (args.j[k].dst == a.dst)
-                args.j[k].in_group = 1;
-        args.g[args.n_groups++] = g;
-        }
-    // measured (profiles/r01_unpack_sweep.log): the unpack wants more resident workgroups than the
-    // pack -- 512-row tiles x 8 workgroups per CU beat 1024 x 4 by 8 % at 10 M rows; launches too small
-    // to fill the chip twice keep the larger tile
-    uint32_t tile = 16, tile_cap = N > (1ull << 21) ? 512 : 1024;
-    uint64_t per_cu = 8;
-    const PackTuning tune = tuning(); // tuning sweeps (tools/unpack_bench.py)
-    if (tune.unpack_tile_cap)
-        tile_cap = tune.unpack_tile_cap;
-    per_cu = tune.unpack_per_cu;
-    while (tile * 2 <= tile_cap && (uint64_t)tile * 2 * sum_rowbytes <= UNPACK_LDS_BYTES)
-        tile <<= 1;
-    args.tile_rows = tile;
-    args.n_tiles = (N + tile - 1) / tile;
-    size_t lds_bytes = UNPACK_TABLE_BYTES; // the column table of the kernel sits in front
-    for (uint32_t i = 0; i < args.n_jobs; i++)
-        {
-        args.j[i].lds_off = (uint32_t)lds_bytes;
-        lds_bytes += (size_t)tile * args.j[i].rowbytes; // tile is a multiple of 16: stays 16-byte aligned
-        }
-    uint64_t resident = lds_bytes ? (160u * 1024u) / lds_bytes : 8;
-    uint64_t blocks = args.n_tiles;
-    uint64_t cap = (uint64_t)num_cus() * std::max<uint64_t>(1, std::min<uint64_t>(per_cu, resident));
-    if (blocks > cap)
-        blocks = cap;
-    if (w32)
-        hipLaunchKernelGGL(unpack_tiles_kernel<true>, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
-    else
-        hipLaunchKernelGGL(unpack_tiles_kernel<false>, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
-    }
-
-int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
-    {
-    if (n_jobs == 0 || N == 0)
-        return PGSD_SUCCESS;
-    std::vector<UnpackJob> all;
-    all.reserve(n_jobs);
-    for (uint32_t i = 0; i < n_jobs; i++)
-        {
-        const pgsd_unpack_job& q = jobs[i];
-        const uint32_t ssz = (uint32_t)sizeof_type(q.src_type), dsz = (uint32_t)sizeof_type(q.dst.dst_type);
-        const bool s_int = q.src_type <= PGSD_TYPE_INT64, d_int = q.dst.dst_type <= PGSD_TYPE_INT64;
-        bool ok = q.src && q.dst.dst && ssz && dsz && q.M && q.M <= PACK_MAX_M
-                  && q.dst.dst_col0 + q.M <= q.dst.dst_stride && (((uintptr_t)q.src) & 15) == 0
-                  && (((uintptr_t)q.dst.dst) & (dsz - 1)) == 0 && (uint64_t)q.M * ssz <= PACK_MAX_ROWBYTES;
-        if (q.dst.bitcast)
-            ok = ok && ssz == dsz;
-        else
-            ok = ok && !(!s_int && d_int) && !(s_int && !d_int && ssz == 8);
-        ok = ok && !(q.dst.fill_rest && q.dst.dst_stride > 32); // the fill addresses columns with a 32-bit mask
-        if (!ok)
-            {
-            if (err)
-                *err = "invalid unpack job (types, columns, alignment or pointers)";
-            return PGSD_ERROR_INVALID_ARGUMENT;
-            }
-        UnpackJob j;
-        memset(&j, 0, sizeof(j));
-        j.src = q.src;
-        j.dst = q.dst.dst;
-        j.order = q.dst.order;
-        j.M = q.M;
-        j.ssz = ssz;
-        j.dsz = dsz;
-        j.kind = conv_kind(q.src_type, q.dst.dst_type, q.dst.bitcast);
-        j.dst_stride = q.dst.dst_stride;
-        j.dst_col0 = q.dst.dst_col0;
-        j.magic = q.M == 1 ? 0u : (uint32_t)(((1ull << 32) + q.M - 1) / q.M);
-        j.rowbytes = q.M * ssz;
-        j.fill_rest = q.dst.fill_rest ? 1u : 0u;
-        j.fill_bits = q.dst.fill_bits;
-        all.push_back(j);
-        }
-    // chunks of one destination array next to each other (their relative order is kept)
-    std::stable_sort(all.begin(), all.end(), [](const UnpackJob& a, const UnpackJob& b) { return (uintptr_t)a.dst < (uintptr_t)b.dst; });
-    // 1. destination arrays the row-per-lane kernel takes: rows of four 4-byte elements (or four doubles
-    //    restored from f32 chunks) fed by one or two chunks of 4-byte elements on disjoint columns, no
-    //    scatter index; plus dense same-type arrays (the chunk IS the array).  One launch per conversion
-    //    class; everything else goes to the LDS-tiled kernel below.
-    if (N < (1ull << 31) && !tuning().unpack_tiles)
-        {
-        std::vector<bool> taken(all.size(), false);
-        for (int f64 = 0; f64 < 2; f64++)
-            {
-            while (true)
-                {
-                UnrowsPlan plan;
-                memset(&plan.args, 0, sizeof(plan.args));
-                plan.args.N = N;
-                plan.f64 = f64 != 0;
-                for (size_t i = 0; i < all.size();)
-                    {
-                    size_t e = i; // [i, e) = the chunks of one destination array (sorted by dst, order kept)
-                    while (e < all.size() && all[e].dst == all[i].dst)
-                        e++;
-                    const UnpackJob& j0 = all[i];
-                    const size_t n = e - i;
-                    bool ok = !taken[i] && n <= 2 && plan.args.n_groups < ROWS_MAX_GROUPS && (((uintptr_t)j0.dst) & 15) == 0;
-                    for (size_t k = i; k < e && ok; k++)
-                        {
-                        const UnpackJob& j = all[k];
-                        ok = j.order == nullptr && j.dst_stride == j0.dst_stride && j.dsz == j0.dsz
-                             && (((uintptr_t)j.src) & 15) == 0;
-                        }
-                    // a dense array of the chunk's own type (any element size, any row width): a plain copy
-                    const bool dense = ok && n == 1 && j0.kind == PACK_BITS && j0.ssz == j0.dsz && j0.dst_col0 == 0
-                                       && j0.M == j0.dst_stride;
-                    if (dense)
-                        ok = f64 == 0; // rides along in the launch of the first pass
-                    else if (ok)
-                        {
-                        ok = j0.dst_stride == 4 && (f64 ? j0.dsz == 8 : j0.dsz == 4);
-                        for (size_t k = i; k < e && ok; k++)
-                            ok = all[k].ssz == 4 && all[k].kind == (uint32_t)(f64 ? PACK_F2F : PACK_BITS) && all[k].M <= 4;
-                        if (ok && n == 2) // disjoint columns: no "later chunk wins" question inside a row
-                            ok = all[i].dst_col0 + all[i].M <= all[i + 1].dst_col0
-                                 || all[i + 1].dst_col0 + all[i + 1].M <= all[i].dst_col0;
-                        }
-                    if (ok)
-                        {
-                        UnrowsGroup& g = plan.args.g[plan.args.n_groups++];
-                        g.dst = j0.dst;
-                        g.a = j0.src;
-                        for (size_t k = i; k < e && !dense; k++)
-                            if (all[k].fill_rest && !g.fill_on)
-                                {
-                                g.fill_on = 1;
-                                g.fill_lo = (uint32_t)all[k].fill_bits;
-                                g.fill_hi = (uint32_t)(all[k].fill_bits >> 32);
-                                }
-                        if (dense)
-                            {
-                            const uint64_t bytes = N * (uint64_t)j0.M * j0.ssz;
-                            g.copy_vecs = bytes >> 4;
-                            g.copy_tail = (uint32_t)(bytes & 15);
-                            }
-                        else
-                            {
-                            // `a` = the chunk of the lower columns (xyz before w: the kernel's static hot shape)
-                            const UnpackJob& lo = (n == 2 && all[i + 1].dst_col0 < j0.dst_col0) ? all[i + 1] : j0;
-                            g.a = lo.src;
-                            g.a_nw = lo.M;
-                            g.a_col0 = lo.dst_col0;
-                            if (n == 2)
-                                {
-                                const UnpackJob& hi = (&lo == &j0) ? all[i + 1] : j0;
-                                g.b = hi.src;
-                                g.b_nw = hi.M;
-                                g.b_col0 = hi.dst_col0;
-                                }
-                            }
-                        for (size_t k = i; k < e; k++)
-                            taken[k] = true;
-                        }
-                    i = e;
-                    }
-                if (plan.args.n_groups == 0)
-                    break;
-                launch_unrows(plan, N, stream);
-                }
-            }
-        std::vector<UnpackJob> rest;
-        for (size_t i = 0; i < all.size(); i++)
-            if (!taken[i])
-                rest.push_back(all[i]);
-        all.swap(rest);
-        }
-    // fills the remaining (tiled / generic) chunks asked for: one pass per destination array over the columns
-    // none of ITS chunks writes, ahead of the chunks on the stream
-    for (size_t i = 0; i < all.size();)
-        {
-        size_t e = i;
-        while (e < all.size() && all[e].dst == all[i].dst)
-            e++;
-        uint32_t covered = 0;
-        const UnpackJob* want = nullptr;
-        for (size_t k = i; k < e; k++)
-            {
-            for (uint32_t c = 0; c < all[k].M && all[k].dst_col0 + c < 32; c++)
-                covered |= 1u << (all[k].dst_col0 + c);
-            if (all[k].fill_rest && !want)
-                want = &all[k];
-            }
-        if (want && want->dst_stride <= 32)
-            {
-            FillArgs fa;
-            memset(&fa, 0, sizeof(fa));
-            fa.dst = want->dst;
-            fa.order = want->order;
-            fa.N = N;
-            fa.bits = want->fill_bits;
-            fa.stride = want->dst_stride;
-            fa.dsz = want->dsz;
-            fa.colmask = ~covered & (want->dst_stride >= 32 ? 0xffffffffu : ((1u << want->dst_stride) - 1u));
-            if (fa.colmask)
-                {
-                const uint64_t lanes = N * (uint64_t)fa.stride;
-                hipLaunchKernelGGL(fill_cols_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, fa);
-                }
-            }
-        i = e;
-        }
-    std::vector<UnpackJob> batch;
-    uint32_t sum_rowbytes = 0;
-    for (size_t i = 0; i < all.size(); i++)
-        {
-        const UnpackJob& j = all[i];
-        // a chunk that rewrites columns an earlier chunk of the batch wrote goes to the next launch:
-        // "the later chunk wins" then holds by stream order
-        bool overlap = false;
-        for (const UnpackJob& b : batch)
-            if (b.dst == j.dst && j.dst_col0 < b.dst_col0 + b.M && b.dst_col0 < j.dst_col0 + j.M)
-                overlap = true;
-        if (!batch.empty()
-            && (overlap || batch.size() == UNPACK_MAX_JOBS || sum_rowbytes + j.rowbytes > UNPACK_MAX_SUM_ROWBYTES))
-            {
-            launch_unpack_batch(batch, N, stream);
-            batch.clear();
-            sum_rowbytes = 0;
-            }
-        batch.push_back(j);
-        sum_rowbytes += j.rowbytes;
-        }
-    if (!batch.empty())
-        launch_unpack_batch(batch, N, stream);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        {
-        if (err)
-            *err = std::string("unpack kernel launch failed: ") + hipGetErrorString(e);
-        return PGSD_ERROR_DEVICE;
-        }
-    return PGSD_SUCCESS;
-    }
     } // namespace pgsd_amd
 
 using namespace pgsd_amd;
-
-extern "C" int pgsd_unpack_fields(uint32_t n_jobs, const struct pgsd_unpack_job* jobs, uint64_t N, void* stream)
-    try
-    {
-    if (n_jobs > 0 && !jobs)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    if (!pgsd_device_available())
-        {
-        set_last_error("pgsd_unpack_fields: no HIP device visible (the HIP path has no CPU fallback)");
-        return PGSD_ERROR_NO_DEVICE;
-        }
-    std::string err;
-    int rc = launch_unpack(n_jobs, jobs, N, (hipStream_t)stream, &err);
-    if (rc != PGSD_SUCCESS)
-        set_last_error(err);
-    return rc;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
 
 extern "C" int pgsd_device_available(void)
     try
@@ -2420,97 +1095,6 @@ catch (...)
 
 // scratch space of pgsd_select_rows: the library's, one per device, grown on demand (a call holds the lock: it ends
 // with a stream synchronisation anyway)
-namespace
-    {
-struct SelectScratch
-    {
-    void* dev = nullptr;
-    size_t cap = 0;
-    uint64_t* host_count = nullptr; // pinned
-    };
-std::mutex g_select_lock;
-std::map<int, SelectScratch> g_select_scratch;
-    } // namespace
-
-extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_index, uint64_t* out_count_host, void* stream_)
-    try
-    {
-    if (!out_count_host || (N > 0 && (!flags || !out_index)) || N >= (1ull << 32))
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    if (!pgsd_device_available())
-        {
-        set_last_error("pgsd_select_rows: no HIP device visible (the HIP path has no CPU fallback)");
-        return PGSD_ERROR_NO_DEVICE;
-        }
-    if (N == 0)
-        {
-        *out_count_host = 0;
-        return PGSD_SUCCESS;
-        }
-    std::lock_guard<std::mutex> guard(g_select_lock);
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess)
-        return PGSD_ERROR_DEVICE;
-    SelectScratch& sc = g_select_scratch[device];
-        {
-        uint64_t nb = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
-        // the count (u64) + block_counts (u32) rounded to 8 bytes + block_offsets (u64)
-        const size_t need = 8 + (size_t)(((nb * 4 + 7) & ~7ull) + nb * 8);
-        if (need > sc.cap)
-            {
-            if (sc.dev)
-                (void)hipFree(sc.dev);
-            sc.dev = nullptr;
-            sc.cap = 0;
-            const size_t cap = std::max<size_t>(need * 2, 1u << 16);
-            if (hipMalloc(&sc.dev, cap) != hipSuccess)
-                {
-                set_last_error("pgsd_select_rows: cannot allocate the scratch space");
-                return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
-                }
-            sc.cap = cap;
-            }
-        if (!sc.host_count && hipHostMalloc((void**)&sc.host_count, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess)
-            {
-            set_last_error("pgsd_select_rows: cannot allocate pinned memory");
-            return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
-            }
-        }
-    uint64_t* out_count = (uint64_t*)sc.dev;
-    void* workspace = (char*)sc.dev + 8;
-    hipStream_t stream = (hipStream_t)stream_;
-    uint64_t n_blocks = (N + SEL_PER_BLOCK - 1) / SEL_PER_BLOCK;
-        {
-        uint32_t* block_counts = (uint32_t*)workspace;
-        uint64_t* block_offsets = (uint64_t*)((char*)workspace + ((n_blocks * 4 + 7) & ~7ull));
-        hipLaunchKernelGGL(select_count_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags, N,
-                           block_counts);
-        hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, block_counts,
-                           (uint32_t)n_blocks, block_offsets, out_count);
-        hipLaunchKernelGGL(select_scatter_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags,
-                           N, block_offsets, out_index);
-        }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        {
-        set_last_error(std::string("select kernel launch failed: ") + hipGetErrorString(e));
-        return PGSD_ERROR_DEVICE;
-        }
-    e = hipMemcpyAsync(sc.host_count, out_count, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(stream);
-    if (e != hipSuccess)
-        {
-        set_last_error(std::string("pgsd_select_rows: ") + hipGetErrorString(e));
-        return PGSD_ERROR_DEVICE;
-        }
-    *out_count_host = *sc.host_count;
-    return PGSD_SUCCESS;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
 
 extern "C" void pgsd_reload_tuning(void)
     try
@@ -2529,96 +1113,3 @@ extern "C" uint32_t pgsd_abi_version(void)
 
 // Device memory owned by the library (include/pgsd.h): what pgsd.fl / pgsd.hoomd keep elision references, device
 // reads and index lists in, so that the Python device path needs no tensor library.
-extern "C" void* pgsd_device_alloc(int device, size_t bytes, const void* pattern, size_t pattern_bytes)
-    try
-    {
-    if (!pgsd_device_available())
-        {
-        set_last_error("pgsd_device_alloc: no HIP device visible (the HIP path has no CPU fallback)");
-        return nullptr;
-        }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (device >= 0 && device != prev && hipSetDevice(device) != hipSuccess)
-        {
-        set_last_error("pgsd_device_alloc: no device " + std::to_string(device));
-        return nullptr;
-        }
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
-    if (e == hipSuccess && pattern && pattern_bytes > 0 && bytes > 0)
-        {
-        // the pattern repeated over a host image of at most 1 MiB (a multiple of the pattern), copied piecewise
-        const size_t reps = std::max<size_t>(1, std::min<size_t>((1u << 20) / pattern_bytes, (bytes + pattern_bytes - 1) / pattern_bytes));
-        std::vector<char> img(reps * pattern_bytes);
-        for (size_t r = 0; r < reps; r++)
-            memcpy(img.data() + r * pattern_bytes, pattern, pattern_bytes);
-        for (size_t at = 0; at < bytes && e == hipSuccess; at += img.size())
-            e = hipMemcpy((char*)p + at, img.data(), std::min(img.size(), bytes - at), hipMemcpyHostToDevice);
-        }
-    if (e != hipSuccess)
-        {
-        set_last_error(std::string("pgsd_device_alloc: ") + hipGetErrorString(e));
-        if (p)
-            (void)hipFree(p);
-        p = nullptr;
-        }
-    if (device >= 0 && prev >= 0 && device != prev)
-        (void)hipSetDevice(prev);
-    return p;
-    }
-catch (...)
-    {
-        pgsd_amd::abi_guard();
-        return nullptr;
-    }
-
-extern "C" int pgsd_device_free(int device, void* ptr)
-    try
-    {
-    if (!ptr)
-        return PGSD_SUCCESS;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (device >= 0 && device != prev)
-        (void)hipSetDevice(device);
-    const hipError_t e = hipFree(ptr);
-    if (device >= 0 && prev >= 0 && device != prev)
-        (void)hipSetDevice(prev);
-    if (e != hipSuccess)
-        {
-        set_last_error(std::string("pgsd_device_free: ") + hipGetErrorString(e));
-        return PGSD_ERROR_DEVICE;
-        }
-    return PGSD_SUCCESS;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }
-
-extern "C" int pgsd_device_copy(int device, void* dst, const void* src, size_t bytes)
-    try
-    {
-    if (bytes == 0)
-        return PGSD_SUCCESS;
-    if (!dst || !src)
-        return PGSD_ERROR_INVALID_ARGUMENT;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (device >= 0 && device != prev)
-        (void)hipSetDevice(device);
-    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDefault); // either side may be host memory
-    if (device >= 0 && prev >= 0 && device != prev)
-        (void)hipSetDevice(prev);
-    if (e != hipSuccess)
-        {
-        set_last_error(std::string("pgsd_device_copy: ") + hipGetErrorString(e));
-        return PGSD_ERROR_DEVICE;
-        }
-    return PGSD_SUCCESS;
-    }
-catch (...)
-    {
-        return pgsd_amd::abi_guard();
-    }

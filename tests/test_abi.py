@@ -106,3 +106,17 @@ def test_rccl_library_override_is_honoured_and_fails_loudly():
     assert p.returncode == 0, p.stderr[-1000:]
     rc, msg = p.stdout.strip().split(" ", 1)
     assert int(rc) != 0 and "PGSD_RCCL_LIBRARY" in msg and "/nonexistent/librccl.so" in msg
+
+
+def test_device_buffer_fails_loudly_without_a_gpu():
+    """pgsd.fl.DeviceBuffer is device memory owned by the library (pgsd_device_alloc): no host stand-in."""
+    import numpy as np
+    import pytest
+    import pgsd.fl as fl
+    from pgsd import _lib
+    if _lib.lib.pgsd_device_available():
+        return
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        fl.DeviceBuffer((16,), np.float32)
+    with pytest.raises(ValueError):
+        fl.select_rows(np.ones(8, dtype=np.uint8))          # host memory is not a flags array on the GPU

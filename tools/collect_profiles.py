@@ -69,8 +69,11 @@ if fc and wc:
     write = {k: [float(r["Counter_Value"]) for r in v] for k, v in pack_rows(wc, "WRITE_SIZE").items()}
     fk = sum(statistics.median(v) for v in fetch.values())
     wk = sum(statistics.median(v) for v in write.values())
-    with open(os.path.join(ROOT, "pgsd-sph_amd", "csrc", "pgsd_pack.hip"), "rb") as f:
-        sha = hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()       # = bench.py's pack_source_sha256()
+    for name in ("pgsd_pack.hip", "pgsd_kernels.hpp"):
+        with open(os.path.join(ROOT, "pgsd-sph_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    sha = h.hexdigest()
     tj = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --particles "
                   "10000000 --steps 10 --warmup 2`, round %s (median over the dispatches); raw rows in profiles/%s_pmc_"
