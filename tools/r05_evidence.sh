@@ -13,6 +13,10 @@ if [ "$PART" = 1 ]; then
   ( cd $R && timeout -k 10 300 python3 bench.py > $O/bench_n1_final.json 2> $O/bench_n1_final.err ); echo "bench rc=$?"
   ( cd $R && timeout -k 10 500 bash tools/profile_pack.sh r05 > $O/profile_pack.log 2>&1 ); echo "profile_pack rc=$?"
   ( cd $R && timeout -k 10 300 bash tools/profile_legs.sh r05 > $O/profile_legs.log 2>&1 ); echo "profile_legs rc=$?"
+  # config 4 as a headline run of its own, with the reference's CPU path of the same schema beside it
+  for schema in sph union; do
+    ( cd $R && timeout -k 10 300 python3 bench.py --schema $schema --steps 6 --warmup 2 --traffic off --no-stall-test --no-exchange-probe > $O/bench_$schema.json 2> $O/bench_$schema.err ); echo "bench $schema rc=$?"
+  done
 elif [ "$PART" = 2 ]; then
   ( cd $R && timeout -k 10 600 bash tools/rehearse_ranks.sh > $O/rehearse.log 2>&1 ); echo "rehearse rc=$?"
   cd /tmp && export TMPDIR=/tmp
