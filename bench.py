@@ -35,11 +35,42 @@ ALGO_BYTES_PER_PARTICLE = 56   # read pos.xyz + vel.xyz + typeid (28 B) + write 
 PAYLOAD_BYTES_PER_PARTICLE = 28
 
 
+def numa_local_cores(n_ranks):
+    """One host core per rank, taken from the NUMA-local cores of GPU r (r = 0 .. n_ranks - 1; sysfs
+    /sys/bus/pci/devices/<bdf>/local_cpulist) -- SURVEY 8(d): the CPU baseline runs 'one host process per GPU pinned to
+    that GPU's NUMA-local cores'.  None when the topology cannot be read (then the ranks are bound to consecutive cores)."""
+    try:
+        import torch
+
+        def cpus(text):
+            out = []
+            for part in text.strip().split(","):
+                a, _, b = part.partition("-")
+                out += list(range(int(a), int(b or a) + 1))
+            return out
+
+        allowed = set(os.sched_getaffinity(0))
+        taken, cores = set(), []
+        for r in range(n_ranks):
+            p = torch.cuda.get_device_properties(r % max(torch.cuda.device_count(), 1))
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as fh:
+                local = [c for c in cpus(fh.read()) if c in allowed and c not in taken]
+            if not local:
+                return None
+            cores.append(local[0])
+            taken.add(local[0])
+        return cores
+    except Exception:  # no sysfs entry, an older torch without the pci_* properties, a masked affinity ...
+        return None
+
+
 def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
     """Time the reference ITSELF (oracle/_ref/ref_bench = the reference's pgsd.c compiled in the
     build container + tests/drivers/ref_bench.c) under MPICH on this host's cores: `ranks` MPI ranks
-    (one core each, one per GPU of the run, as SURVEY 8(d) prescribes; `mpiexec -bind-to core`: every rank
-    pinned to a core of its own) writing `n_particles` each, plus a second run on more ranks
+    (one core each, one per GPU of the run, as SURVEY 8(d) prescribes: rank r pinned to a core of GPU r's NUMA node,
+    `mpiexec -bind-to user:<cores>`; consecutive cores, `-bind-to core`, where the topology cannot be read) writing
+    `n_particles` each, plus a second run on more ranks
     (min(4 * ranks, nproc)) of the same total workload to show what more cores buy.  None when it cannot run."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
@@ -50,9 +81,13 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
     more = min(4 * ranks, nproc)
     path = os.path.join(out_dir, "pgsd_bench_ref_%d.gsd" % os.getpid())
     res = {}
+    cores = numa_local_cores(ranks)
+    binding = ("rank r bound to core %s: a core of GPU r's NUMA node (mpiexec -bind-to user:...)" % ",".join(map(str, cores))
+               if cores else "mpiexec -bind-to core (one core per rank; GPU topology not readable: not NUMA-matched)")
     try:
         for r in sorted({ranks, more}):
-            out = subprocess.run([mpiexec, "-bind-to", "core", "-n", str(r), exe, str(n_particles * ranks), str(frames),
+            bind = ["-bind-to", "user:" + ",".join(map(str, cores))] if (cores and r == ranks) else ["-bind-to", "core"]
+            out = subprocess.run([mpiexec] + bind + ["-n", str(r), exe, str(n_particles * ranks), str(frames),
                                   path, schema], capture_output=True, timeout=300, check=True).stdout.decode()
             res[r] = json.loads(out.strip().splitlines()[-1])
     except Exception as e:  # missing MPI runtime, time-out, ...
@@ -64,14 +99,14 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
     return {"value": round(res[ranks]["GBps"], 4), "unit": "GB/s", "cores": ranks, "kind": "reference",
             "nproc": nproc, "ranks": ranks,
             "more_cores": {"ranks": more, "value": round(res[more]["GBps"], 4)},
-            "binding": "mpiexec -bind-to core (one core per rank; not NUMA-matched to the GPUs)", "schema": schema,
+            "binding": binding, "schema": schema,
             "sample": "%d frames x %d particles per rank (%s): C pack loop out of float4 arrays + the "
                       "reference's pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), %d rank(s) = %d core(s) of %d, "
-                      "each rank bound to a core of its own (mpiexec -bind-to core), "
+                      "each rank bound to a core of its own (%s), "
                       "one shared file on %s; the same total workload on %d ranks: %.3f GB/s"
                       % (frames, n_particles, {"pvi": "pos+vel+typeid", "sph": "the 14 chunks of the SPH schema, 112 B/particle",
                                                "union": "the 19 chunks of SPH + upstream HOOMD, 164 B/particle"}[schema],
-                         ranks, ranks, nproc, out_dir, more, res[more]["GBps"])}
+                         ranks, ranks, nproc, binding, out_dir, more, res[more]["GBps"])}
 
 
 def cpu_baseline(n_particles, frames, out_dir):

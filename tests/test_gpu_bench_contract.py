@@ -41,7 +41,7 @@ def test_bench_line_has_the_contracts_fields():
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "GB/s" and c["value"] > 0
     assert isinstance(c["sample"], str) and "particles" in c["sample"]
     if c["kind"] == "reference":                    # ranks pinned, and the line says how
-        assert "bind-to core" in c["sample"] and "bind-to core" in c["binding"]
+        assert "bind-to" in c["sample"] and "bind-to" in c["binding"]     # "user:<cores of the GPU's NUMA node>" or "core"
     assert "legs" not in d                          # --no-legs
     # what a draining snapshot costs a kernel that runs beside it (the copies are shader blits): measured, not assumed
     o = d["snapshot_overlap"]
