@@ -82,8 +82,8 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
     path = os.path.join(out_dir, "pgsd_bench_ref_%d.gsd" % os.getpid())
     res = {}
     cores = numa_local_cores(ranks)
-    binding = ("rank r bound to core %s: a core of GPU r's NUMA node (mpiexec -bind-to user:...)" % ",".join(map(str, cores))
-               if cores else "mpiexec -bind-to core (one core per rank; GPU topology not readable: not NUMA-matched)")
+    binding = ("mpiexec -bind-to user:%s (rank r on a core of GPU r's NUMA node)" % ",".join(map(str, cores))
+               if cores else "mpiexec -bind-to core (GPU topology not readable: not NUMA-matched)")
     try:
         for r in sorted({ranks, more}):
             bind = ["-bind-to", "user:" + ",".join(map(str, cores))] if (cores and r == ranks) else ["-bind-to", "core"]
@@ -100,13 +100,12 @@ def cpu_baseline_reference(n_particles, frames, out_dir, ranks=1, schema="pvi"):
             "nproc": nproc, "ranks": ranks,
             "more_cores": {"ranks": more, "value": round(res[more]["GBps"], 4)},
             "binding": binding, "schema": schema,
-            "sample": "%d frames x %d particles per rank (%s): C pack loop out of float4 arrays + the "
-                      "reference's pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), %d rank(s) = %d core(s) of %d, "
-                      "each rank bound to a core of its own (%s), "
-                      "one shared file on %s; the same total workload on %d ranks: %.3f GB/s"
-                      % (frames, n_particles, {"pvi": "pos+vel+typeid", "sph": "the 14 chunks of the SPH schema, 112 B/particle",
-                                               "union": "the 19 chunks of SPH + upstream HOOMD, 164 B/particle"}[schema],
-                         ranks, ranks, nproc, binding, out_dir, more, res[more]["GBps"])}
+            "sample": "%d frames x %d particles per rank (%s): C pack loop out of float4 arrays + the reference's "
+                      "pgsd_write_chunk/pgsd_end_frame (MPICH 3.3.2 MPI-IO), %d rank(s) = %d bound core(s) of %d (-bind-to), "
+                      "one shared file on %s; same workload on %d ranks: %.3f GB/s"
+                      % (frames, n_particles, {"pvi": "pos+vel+typeid", "sph": "14 SPH chunks, 112 B/particle",
+                                               "union": "19 chunks SPH + upstream HOOMD, 164 B/particle"}[schema],
+                         ranks, ranks, nproc, out_dir, more, res[more]["GBps"])}
 
 
 def cpu_baseline(n_particles, frames, out_dir):
@@ -704,8 +703,8 @@ def main():
                      "kernel": PACK_KERNEL, "avg_ms": round(pack_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bpp * N},
         "pack_aggregate": {"algorithmic_GBps": round(world * achieved, 1), "launches_per_rank": int(stats["pack_launches"]),
-                           "note": "n_gpus x the slowest rank's pack kernel rate: a sum of independent per-GPU rates "
-                                   "(nothing shared is measured by it); `value` is the shared-file rate"},
+                           "note": "n_gpus x the slowest rank's pack kernel rate (independent per-GPU rates, nothing shared); "
+                                   "`value` is the shared-file rate"},
         "snapshot_stall_ms": stall_ms,
         "snapshot_overlap_slowdown_pct": overlap["slowdown_pct"] if overlap else None,
         "snapshot_overlap": overlap,
@@ -733,6 +732,8 @@ def main():
             out["legs"], out["legs_traffic_source"] = bench_legs.run_legs(N, args.dir, target_fstype,
                                                                           traffic=(args.traffic == "live" and not under_a_profiler()))
             out["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
+            # ... and their essentials as flat scalars inside `roofline` (what the driver's record keeps of the line)
+            out["roofline"].update(bench_legs.flat_summary(out["legs"]))
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -174,9 +174,9 @@ def timed_pack(arr_sets, N, launches, warmup, _lib):
 def leg_entry(name, kernel, ms_list, algo_bytes, **more):
     import statistics
     avg = sum(ms_list) / len(ms_list)
+    # compact on purpose: the driver keeps a bounded tail of stdout; what each leg IS stands in this file's docstring
     d = {"name": name, "kernel": kernel, "launches": len(ms_list), "avg_us": round(avg * 1e3, 2),
          "median_us": round(statistics.median(ms_list) * 1e3, 2), "algorithmic_bytes": int(algo_bytes),
-         "achieved_GBps": round(algo_bytes / (avg * 1e-3) / 1e9, 1),
          "frac": round(algo_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
     d.update(more)
     return d
@@ -217,25 +217,17 @@ def leg_config2(torch, np, fl, _lib):
         keep += [pos, vel, tid, k2]
     dbl = timed_pack(dsets, N, 100, 10, _lib)
     import statistics
-    e = leg_entry("config2", "pack_rows_kernel", rot, 56 * N,
-                  workload="2^20 particles, float4 pos + float4 vel + uint32 id -> N x 3, N x 3, N x 1; kernel only",
-                  protocol="200 launches after 20 warm-ups, 11 buffer sets rotated (704 MiB: no byte re-read from the "
-                           "256 MiB Infinity Cache), dispatch-stamped (SURVEY 8(d))",
-                  target_frac=0.70,
-                  unrotated={"avg_us": round(sum(unrot) / len(unrot) * 1e3, 2),
-                             "median_us": round(statistics.median(unrot) * 1e3, 2),
-                             "frac": round(56 * N / (sum(unrot) / len(unrot) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "what": "the same 200 launches on ONE buffer set (64 MiB: Infinity-Cache resident, what a "
-                                     "simulation that has just written the arrays sees)"},
-                  hoomd_layout={"avg_us": round(sum(hoomd) / len(hoomd) * 1e3, 2),
-                                "median_us": round(statistics.median(hoomd) * 1e3, 2),
-                                "frac": round(56 * N / (sum(hoomd) / len(hoomd) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "what": "type id kept in position.w (HOOMD's Scalar4 layout): two source arrays, 60 B moved "
-                                        "per particle; same protocol"},
-                  double4={"avg_us": round(sum(dbl) / len(dbl) * 1e3, 2),
-                           "algorithmic_bytes": (24 + 24 + 4 + 28) * N,
-                           "frac": round(80 * N / (sum(dbl) / len(dbl) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "what": "double4 pos / vel written as float32 chunks, 7 buffer sets rotated"})
+    def us(x):
+        return round(sum(x) / len(x) * 1e3, 2)
+
+    # protocol: 200 launches after 20 warm-ups, 11 buffer sets rotated (704 MiB: no byte re-read from the
+    # 256 MiB Infinity Cache), dispatch-stamped.  unrotated: the same on ONE set (Infinity-Cache resident: what a simulation
+    # that has just written the arrays sees).  hoomd_layout: type id kept in position.w (two source arrays, 60 B moved per
+    # particle).  double4: double4 pos / vel written as float32 chunks (80 algorithmic B/particle), 7 sets rotated.
+    e = leg_entry("config2", "pack_rows_kernel", rot, 56 * N, rows=N, buffer_sets=n_sets, target_frac=0.70,
+                  unrotated_us=us(unrot), hoomd_layout_us=us(hoomd),
+                  hoomd_layout_frac=round(56 * N / (us(hoomd) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                  double4_us=us(dbl), double4_frac=round(80 * N / (us(dbl) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
     del keep
     return e
 
@@ -279,16 +271,11 @@ def run_frames(schema, N, steps, warmup, out_dir, torch, np, fl, tag):
 
 def leg_config4(schema, N, out_dir, fstype, torch, np, fl):
     r = run_frames(schema, N, 3, 1, out_dir, torch, np, fl, schema)
-    e = leg_entry("config4_" + schema, "pack_rows_kernel + pack_copy_kernel (one fused launch pair per frame)",
-                  [r["pack_ms_per_frame"]], r["algo_bpp"] * N,
-                  workload="%d particles, %s" % (N, r["layout"]),
-                  value_GBps=round(3 * N * r["payload_bpp"] / r["dt"] / 1e9, 3), frames=3,
-                  ms_per_frame=round(r["dt"] / 3 * 1e3, 2), payload_bytes_per_frame=N * r["payload_bpp"],
-                  target_dir=out_dir, target_fstype=fstype,
-                  note="BASELINE config 4 names an NVMe target: these boxes have none, the file goes where the "
-                       "headline's goes (target_fstype)")
+    # (BASELINE config 4 names an NVMe target: these boxes have none, the file goes where the headline's goes)
+    e = leg_entry("config4_" + schema, "pack_rows_kernel", [r["pack_ms_per_frame"]], r["algo_bpp"] * N,
+                  rows=N, value_GBps=round(3 * N * r["payload_bpp"] / r["dt"] / 1e9, 3), frames=3,
+                  ms_per_frame=round(r["dt"] / 3 * 1e3, 2), target_fstype=fstype)
     e["launches"] = 3
-    e["kernels_per_frame"] = r["kernels_per_frame"]
     return e
 
 
@@ -329,13 +316,10 @@ def leg_config5(out_dir, torch, np, fl, _lib, N_file=80_000_000, row0=35_000_000
     del pos, vel
     ms, keep = unpack_launches(n_read, 20, 3, torch, _lib)
     best = min(times[1:])
-    e = leg_entry("config5_read", "unpack_rows_kernel", ms, 56 * n_read,
-                  workload="one frame of %d particles (position, typeid, velocity), rows [%d, %d) -> Scalar4 pos "
-                           "(x, y, z, typeid bits) and Scalar4 vel (vx, vy, vz, 1.0) on the GPU"
-                           % (N_file, row0, row0 + n_read),
-                  file_to_hbm_GBps=round(28 * n_read / best / 1e9, 2), read_ms=[round(t * 1e3, 2) for t in times],
-                  bit_exact=exact, target_dir=out_dir,
-                  timing="unpack kernel: stream events around 20 back-to-back launches over 2 buffer sets (1.2 GB)")
+    # one frame of N_file particles (position, typeid, velocity), rows [row0, row0 + n_read) -> Scalar4 pos (x, y, z, typeid
+    # bits) and Scalar4 vel (vx, vy, vz, 1.0) on the GPU; unpack kernel: stream events around 20 back-to-back launches
+    e = leg_entry("config5_read", "unpack_rows_kernel", ms, 56 * n_read, rows=n_read, file_rows=N_file,
+                  file_to_hbm_GBps=round(28 * n_read / best / 1e9, 2), bit_exact=exact)
     del keep
     return e
 
@@ -401,12 +385,10 @@ def leg_gather(perm, N, torch, np, fl, _lib):
     fields, order, keep = gather_setup(N, perm, torch, np, fl)
     arr, k2 = pack_jobs(fields, N, torch, np, _lib, order=order)
     ms = timed_pack([arr], N, 20, 3, _lib)
-    what = {"uniform": "a uniformly random reverse-tag array (adversarial: every 16-byte row in a 64-byte sector of its own)",
-            "hilbert": "lattice-order tags over Hilbert-curve memory order (what HOOMD's SFC sorter leaves a dump writer)"}[perm]
-    e = leg_entry("gather_" + perm, "pack_tiles_kernel (gather through `order`)", ms, 60 * N,
-                  workload="%d particles, position + typeid + velocity in TAG order: chunk[t] = src[order[t]], order = %s"
-                           % (N, what),
-                  algorithmic="28 B of source columns + 4 B of index + 28 B of chunks per particle")
+    # position + typeid + velocity in TAG order, chunk[t] = src[order[t]]; algorithmic = 28 B of source columns + 4 B of
+    # index + 28 B of chunks per particle.  uniform: adversarial (every 16-byte row in a 64-byte sector of its own);
+    # hilbert: lattice-order tags over Hilbert-curve memory order (what HOOMD's SFC sorter leaves a dump writer)
+    e = leg_entry("gather_" + perm, "pack_tiles_kernel", ms, 60 * N, rows=N)
     del keep, k2
     return e
 
@@ -526,18 +508,29 @@ def add_traffic(legs, N):
             # Uncalibrated for this access shape (MI355X_MICROARCH.md, HBM): both readings are given.
             rd = int(fetch[k] * 1024)
             e["traffic"] = rd + wr
-            e["traffic_detail"] = {"FETCH_SIZE_KiB": round(fetch[k], 1), "WRITE_SIZE_KiB": round(write[k], 1),
-                                   "read_bytes": rd, "read_bytes_if_doubled": 2 * rd, "write_bytes": wr,
-                                   "corrections": "bytes = KiB*1024; FETCH_SIZE NOT doubled (sector reads, not a wide "
-                                                  "coalesced stream)"}
+            e["fetch_KiB"], e["write_KiB"], e["fetch_x2"] = round(fetch[k], 1), round(write[k], 1), False
         else:
             rd = int(fetch[k] * 1024 * 2)
-            e["traffic"] = rd + wr
-            e["traffic_detail"] = {"FETCH_SIZE_KiB": round(fetch[k], 1), "WRITE_SIZE_KiB": round(write[k], 1),
-                                   "read_bytes": rd, "write_bytes": wr,
-                                   "corrections": "bytes = KiB*1024; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)"}
+            e["traffic"] = rd + wr       # bytes = KiB * 1024; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)
+            e["fetch_KiB"], e["write_KiB"], e["fetch_x2"] = round(fetch[k], 1), round(write[k], 1), True
         e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_bytes"], 3)
-    return "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench_legs.py --pmc-child (3 launches per leg)"
+    return "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench_legs.py --pmc-child"
+
+
+def flat_summary(legs):
+    """The legs' essentials as flat scalars for bench.py's `roofline` object (the driver's record keeps the scalar
+    members of `roofline`; nested objects of the line only survive in its bounded stdout tail):
+    legs_<name>_us / _frac / _traffic_ratio."""
+    out = {}
+    for e in legs:
+        if "error" in e:
+            out["legs_%s_error" % e["name"]] = e["error"][:80]
+            continue
+        out["legs_%s_us" % e["name"]] = e["avg_us"]
+        out["legs_%s_frac" % e["name"]] = e["frac"]
+        if e.get("traffic_over_algorithmic") is not None:
+            out["legs_%s_traffic_ratio" % e["name"]] = e["traffic_over_algorithmic"]
+    return out
 
 
 def run_legs(N, out_dir, fstype, traffic=True, only=None):
@@ -556,12 +549,10 @@ def run_legs(N, out_dir, fstype, traffic=True, only=None):
     for name, fn in todo:
         if only and name not in only:
             continue
-        t0 = time.perf_counter()
         try:
             e = fn()
         except Exception as ex:  # a leg that fails is reported, the headline stands
             e = {"name": name, "error": "%s: %s" % (type(ex).__name__, ex)}
-        e["leg_wall_s"] = round(time.perf_counter() - t0, 2)
         legs.append(e)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()

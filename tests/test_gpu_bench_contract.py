@@ -143,14 +143,20 @@ def test_bench_line_carries_a_leg_for_every_other_baseline_config():
         assert abs(e["frac"] - e["algorithmic_bytes"] / (e["avg_us"] * 1e-6) / 8e12) < 2e-3
         assert e["traffic"] is None                 # --traffic off
     c2 = legs["config2"]
-    assert c2["algorithmic_bytes"] == 56 * (1 << 20) and c2["launches"] == 200 and "11 buffer sets" in c2["protocol"]
-    assert c2["unrotated"]["avg_us"] > 0 and c2["double4"]["avg_us"] > 0 and c2["target_frac"] == 0.70
+    assert c2["algorithmic_bytes"] == 56 * (1 << 20) and c2["launches"] == 200 and c2["buffer_sets"] == 11
+    assert c2["unrotated_us"] > 0 and c2["hoomd_layout_us"] > 0 and c2["double4_us"] > 0 and c2["target_frac"] == 0.70
     assert legs["config4_sph"]["algorithmic_bytes"] == 224 * n and legs["config4_union"]["algorithmic_bytes"] == 328 * n
     for k in ("config4_sph", "config4_union"):
         assert legs[k]["frames"] == 3 and legs[k]["value_GBps"] > 0 and legs[k]["target_fstype"] == "tmpfs"
     c5 = legs["config5_read"]
     assert c5["bit_exact"] is True and c5["file_to_hbm_GBps"] > 0 and c5["algorithmic_bytes"] == 56 * n
+    assert c5["file_rows"] == 8 * n and c5["rows"] == n
     assert legs["gather_uniform"]["algorithmic_bytes"] == 60 * n == legs["gather_hilbert"]["algorithmic_bytes"]
+    # the essentials again as flat scalars of `roofline`: what the driver's record keeps of the line
+    r = d["roofline"]
+    for name, e in legs.items():
+        assert r["legs_%s_us" % name] == e["avg_us"] and r["legs_%s_frac" % name] == e["frac"]
+    assert all(not isinstance(v, (dict, list)) for k, v in r.items() if k.startswith("legs_"))
     assert d["legs_wall_s"] > 0
 
 
@@ -164,6 +170,8 @@ def test_legs_measure_their_hbm_traffic():
     assert d["legs_traffic_source"].startswith("live")
     for k in ("config2", "config4_sph", "config4_union", "config5_read"):
         e = legs[k]
-        assert e["traffic"] is not None, e
+        assert e["traffic"] is not None and e["fetch_x2"] is True, e
         assert 0.9 < e["traffic_over_algorithmic"] < 1.35, e
+        assert d["roofline"]["legs_%s_traffic_ratio" % k] == e["traffic_over_algorithmic"]
+    assert legs["gather_uniform"]["fetch_x2"] is False
     assert legs["gather_uniform"]["traffic_over_algorithmic"] > legs["gather_hilbert"]["traffic_over_algorithmic"] * 0.9
