@@ -180,7 +180,8 @@ def pmc_pass(counter, child_args, timeout):
         # the program itself follows `--` (no env/bash hop: the profiler's library has the GPU initialised)
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__)] + child_args
-        r = subprocess.run(cmd, timeout=timeout, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        env = {k: v for k, v in os.environ.items() if k != "PGSD_IO"}      # the counter passes write through the POSIX back end
+        r = subprocess.run(cmd, timeout=timeout, capture_output=True, cwd="/tmp", env=dict(env, TMPDIR="/tmp"))
         if r.returncode != 0:
             return None
         out = {}
@@ -437,6 +438,11 @@ def main():
                     help="pgsd_set_partition instead of the per-frame allgather: every rank's row count is declared once "
                          "(weak scaling: the same on all ranks), frames then cost NO collective (collectives_per_frame 0). "
                          "The default keeps the north_star's shape: one allgather of chunk sizes per frame")
+    ap.add_argument("--io", choices=["posix", "mpiio"], default="posix",
+                    help="file back end: posix = pwrite at the offsets the reference passes to MPI_File_write_at (default); "
+                         "mpiio = those very calls (PGSD_IO=mpiio, plugin libpgsd_amd_mpiio.so); MPI is initialised "
+                         "in-process (MPI_Init_thread through ctypes, every rank a singleton: the file is opened on "
+                         "MPI_COMM_SELF); PGSD_LIBMPI names the libmpi to load")
     ap.add_argument("--no-legs", action="store_true",
                     help="N=1, --schema pvi: skip the `legs` (BASELINE configs 2, 4, 5 and the tag-order gather measured "
                          "after the headline; bench_legs.py)")
@@ -474,6 +480,16 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    mpi = None
+    if args.io == "mpiio":
+        # the caller initialises MPI, as with the reference; MPI_THREAD_SERIALIZED: the pipeline's writer thread calls
+        # into MPI-IO too (the library serialises the calls)
+        os.environ["PGSD_IO"] = "mpiio"
+        mpi = ctypes.CDLL(os.environ.get("PGSD_LIBMPI", "/opt/conda/lib/libmpi.so.12"), mode=ctypes.RTLD_GLOBAL)
+        provided = ctypes.c_int(-1)
+        if mpi.MPI_Init_thread(None, None, 2, ctypes.byref(provided)) != 0 or provided.value < 2:
+            raise SystemExit("bench.py --io mpiio: MPI_Init_thread(MPI_THREAD_SERIALIZED) failed (provided %d)" % provided.value)
 
     import numpy as np
     import torch
@@ -650,6 +666,8 @@ def main():
         pdist.finalize()          # tears down the library's RCCL communicator on every rank
         dist.destroy_process_group()
     if rank != 0:
+        if mpi is not None:
+            mpi.MPI_Finalize()
         return
 
     # N = 1 has no exchange (a single rank skips it).  What ONE 512-byte exchange costs on the RCCL back end is
@@ -689,7 +707,7 @@ def main():
                                       "sph": "the 14 per-particle chunks of the PGSD-SPH schema (112 B/particle)",
                                       "union": "the 19 per-particle chunks of the SPH schema + upstream HOOMD attributes "
                                                "(164 B/particle)"}[args.schema], layout, comm_backend, args.dir),
-                   "schema": args.schema, "target_dir": args.dir, "target_fstype": target_fstype,
+                   "schema": args.schema, "io": args.io, "target_dir": args.dir, "target_fstype": target_fstype,
                    "particles_per_gpu": N, "payload_bytes_per_frame_per_gpu": N * payload_bpp,
                    "parallelism": "particle-partition x%d" % world},
         "comm_backend": comm_backend,
@@ -734,6 +752,8 @@ def main():
             out["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
             # ... and their essentials as flat scalars inside `roofline` (what the driver's record keeps of the line)
             out["roofline"].update(bench_legs.flat_summary(out["legs"]))
+    if mpi is not None:
+        mpi.MPI_Finalize()
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

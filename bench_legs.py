@@ -463,7 +463,8 @@ def pmc_pass(counter, N, timeout):
         # the program itself follows `--` (no env/bash hop: the profiler's library has the GPU initialised)
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", info, "--particles", str(N)]
-        r = subprocess.run(cmd, timeout=timeout, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        env = {k: v for k, v in os.environ.items() if k != "PGSD_IO"}
+        r = subprocess.run(cmd, timeout=timeout, capture_output=True, cwd="/tmp", env=dict(env, TMPDIR="/tmp"))
         if r.returncode != 0 or not os.path.exists(info):
             print("bench_legs: %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-400:]), file=sys.stderr)
             return None
