@@ -59,7 +59,9 @@ template<int U, bool NT> __global__ __launch_bounds__(256) void copy_kernel(cons
         }
     }
 
-template<int U, bool NT> static void run(const char* what, uint64_t moved_bytes, int reps, hipStream_t s)
+// grid_blocks > 0: a persistent-style launch of that many workgroups walking the array with a grid stride (reads and
+// writes interleave in steady state instead of "every workgroup loads, then every workgroup stores")
+template<int U, bool NT> static void run(const char* what, uint64_t moved_bytes, int reps, hipStream_t s, unsigned grid_blocks = 0)
     {
     const uint64_t nvec = moved_bytes / 32; // each vector is read once and written once
     const int n_sets = (int)std::max<uint64_t>(2, (600ull << 20) / moved_bytes + 2);
@@ -73,7 +75,7 @@ template<int U, bool NT> static void run(const char* what, uint64_t moved_bytes,
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const unsigned blocks = (unsigned)((nvec + U * 256 - 1) / (U * 256));
+    const unsigned blocks = grid_blocks ? grid_blocks : (unsigned)((nvec + U * 256 - 1) / (U * 256));
     std::vector<float> us;
     for (int r = 0; r < reps + 5; r++)
         {
@@ -88,8 +90,8 @@ template<int U, bool NT> static void run(const char* what, uint64_t moved_bytes,
     std::sort(us.begin(), us.end());
     const float med = us[us.size() / 2];
     printf("{\"lab\": \"copy_ceiling\", \"what\": \"%s\", \"moved_bytes\": %llu, \"rows_per_lane\": %d, \"nontemporal\": %s, "
-           "\"buffer_sets\": %d, \"median_us\": %.2f, \"min_us\": %.2f, \"TBps\": %.3f, \"frac_of_8TBps\": %.3f}\n",
-           what, (unsigned long long)moved_bytes, U, NT ? "true" : "false", n_sets, med, us[0], moved_bytes / med / 1e6,
+           "\"blocks\": %u, \"buffer_sets\": %d, \"median_us\": %.2f, \"min_us\": %.2f, \"TBps\": %.3f, \"frac_of_8TBps\": %.3f}\n",
+           what, (unsigned long long)moved_bytes, U, NT ? "true" : "false", blocks, n_sets, med, us[0], moved_bytes / med / 1e6,
            moved_bytes / med / 1e6 / 8.0);
     fflush(stdout);
     for (int i = 0; i < n_sets; i++)
@@ -114,5 +116,14 @@ int main(int argc, char** argv)
     run<2, true>("config 2: 2^20 particles (62.9 MB)", 62914560ull, reps * 5, s);
     run<4, true>("config 2: 2^20 particles (62.9 MB)", 62914560ull, reps * 5, s);
     run<4, false>("config 2: 2^20 particles (62.9 MB)", 62914560ull, reps * 5, s);
+    // does ANY launch shape move config 2's bytes faster?  persistent grids (1-8 workgroups per CU), 1-8 vectors per lane
+    for (unsigned per_cu : {1u, 2u, 4u, 8u})
+        {
+        run<1, true>("config 2, persistent grid", 62914560ull, reps * 5, s, 256 * per_cu);
+        run<2, true>("config 2, persistent grid", 62914560ull, reps * 5, s, 256 * per_cu);
+        run<4, true>("config 2, persistent grid", 62914560ull, reps * 5, s, 256 * per_cu);
+        }
+    run<1, true>("config 2: 2^20 particles (62.9 MB)", 62914560ull, reps * 5, s);
+    run<8, true>("config 2: 2^20 particles (62.9 MB)", 62914560ull, reps * 5, s);
     return 0;
     }

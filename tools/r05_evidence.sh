@@ -26,6 +26,7 @@ elif [ "$PART" = 2 ]; then
     timeout -k 10 300 python3 $R/tests/fullsize_ranks_worker.py shm 8 10000000 $what /dev/shm 2>/dev/null | grep RESULT >> $O/fullsize_eight_ranks.txt
   done
   cat $O/fullsize_eight_ranks.txt
+  timeout -k 10 200 $R/tools/labs/build/copy_ceiling 40 > $O/copy_ceiling.jsonl 2> $O/copy_ceiling.err; echo "copy_ceiling rc=$?"
 else
   ( cd $R && PGSD_FUZZ_SEEDS=400 timeout -k 10 1000 python3 -m pytest tests/test_gpu_fuzz.py tests/test_gpu_file_fuzz.py tests/test_gpu_elision_fuzz.py -q -x > $O/gpu_fuzz_campaign.log 2>&1 ); echo "fuzz rc=$?"
   tail -3 $O/gpu_fuzz_campaign.log
