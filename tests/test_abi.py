@@ -120,3 +120,20 @@ def test_device_buffer_fails_loudly_without_a_gpu():
         fl.DeviceBuffer((16,), np.float32)
     with pytest.raises(ValueError):
         fl.select_rows(np.ones(8, dtype=np.uint8))          # host memory is not a flags array on the GPU
+
+
+def test_the_product_builds_without_the_tests_directory(tmp_path):
+    """csrc/Makefile's `all` used to build the scenario drivers and the stand-in librccl out of
+    tests/drivers.  A copy of the tree without tests/ must know how to make `all` (dry run: every prerequisite is either
+    present or has a rule), and the Makefile must not name tests/ at all."""
+    import shutil
+    import subprocess
+    mk = open(os.path.join(product.CSRC, "Makefile")).read()
+    assert "$(ROOT)/tests" not in mk and "tests/drivers" not in mk
+    root = tmp_path / "tree"
+    shutil.copytree(os.path.join(product.ROOT, "include"), root / "include")
+    shutil.copytree(os.path.join(product.ROOT, "pgsd-sph_amd"), root / "pgsd-sph_amd",
+                    ignore=shutil.ignore_patterns("build", "*.so", "__pycache__"))
+    p = subprocess.run(["make", "-n", "-C", str(root / "pgsd-sph_amd" / "csrc"), "all"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-800:]
+    assert "pgsd_pack.hip" in p.stdout and "tests/" not in p.stdout
