@@ -365,8 +365,27 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
         return PGSD_SUCCESS;
         }
     std::lock_guard<std::mutex> guard(g_select_lock);
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess)
+    // the scratch space lives on the GPU the FLAGS live on (a process with several GPUs need not have made it current)
+    int current = 0, device = 0;
+    if (hipGetDevice(&current) != hipSuccess)
+        return PGSD_ERROR_DEVICE;
+    device = current;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, flags) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        device = attr.device;
+    else
+        (void)hipGetLastError();
+    struct DeviceScope // restore the caller's current device on every way out
+        {
+        int back;
+        bool on;
+        ~DeviceScope()
+            {
+            if (on)
+                (void)hipSetDevice(back);
+            }
+        } scope {current, device != current};
+    if (scope.on && hipSetDevice(device) != hipSuccess)
         return PGSD_ERROR_DEVICE;
     SelectScratch& sc = g_select_scratch[device];
         {
