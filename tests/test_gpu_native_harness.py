@@ -126,3 +126,41 @@ def test_elide_harness_writes_only_what_differs_from_frame_0(tmp_path, writers):
             assert f.read_chunk(k, "particles/charge").tobytes() == want.tobytes()
     r = _run_ranks(READ_EXE, [path, "verify"], 3)         # frame 0 holds the arrays the read harness verifies
     assert r["verified"] is True and r["mismatches"] == 0 and r["rows_read"] == n_global
+
+
+DUMP_EXE = os.path.join(product.CSRC, "build", "dump_writer")
+
+
+@pytest.mark.parametrize("ranks,group", [(1, "all"), (1, "fluid"), (2, "fluid"), (3, "all")])
+def test_dump_writer_under_a_running_simulation(tmp_path, ranks, group):
+    """examples/dump_writer.hip: a simulation stepping Scalar4 arrays on its own stream, snapshots gathered into tag
+    order through the reverse-tag array (optionally a group only: pgsd_select_rows), static arrays elided against
+    frame 0 in HBM, ONE collective per frame, asynchronous seals.  The program re-reads its file through the
+    reference's entry points and compares every frame with a host model bit for bit (its exit code and `ok`); here
+    the file is read once more through pgsd.fl and the group's size and the elision are checked from outside."""
+    import numpy as np
+    import pgsd.fl as fl
+    product.build()
+    path = str(tmp_path / "dump.gsd")
+    per_rank, steps, period = 50021, 40, 10
+    d = _run_ranks(DUMP_EXE, [per_rank, steps, period, path, group, "keep"], ranks)
+    frames = steps // period + 1
+    assert d["ok"] is True and d["failed_check"] == 0 and d["ranks"] == ranks and d["frames"] == frames == d["verified_frames"]
+    assert d["pack_launches"] == frames                                  # one fused gather + pack launch per snapshot
+    assert d["chunks_written"] == 5 + 3 * (frames - 1) and d["chunks_elided"] == 2 * (frames - 1), d
+    # the handle's collectives: create/open's two + ONE allgather per frame (several ranks only; close's come later)
+    assert d["collectives_rank0"] == ((2 + frames) if ranks > 1 else 0), d
+    g = np.arange(per_rank * ranks, dtype=np.uint64)
+    types = ((g * np.uint64(2654435761)) >> np.uint64(7)) % np.uint64(3)
+    kept = g if group == "all" else g[types != 2]
+    with fl.open(path, "r") as f:
+        assert f.nframes == frames
+        for k in range(frames):
+            assert int(f.read_chunk(k, "configuration/step")[0]) == k * period
+            assert int(f.read_chunk(k, "particles/N")[0]) == kept.size
+            assert f.chunk_exists(k, "particles/typeid") == (k == 0) == f.chunk_exists(k, "particles/mass")
+            dens = f.read_chunk(k, "particles/density")
+            want = np.float32(1000.0) + np.float32(0.5 * k * period) + (kept % np.uint64(7)).astype(np.float32)
+            assert dens.tobytes() == want.astype(np.float32).tobytes()
+            assert f.read_chunk(k, "particles/position").shape == (kept.size, 3)
+        assert f.read_chunk(0, "particles/typeid").tobytes() == types[np.isin(g, kept)].astype(np.uint32).tobytes()
