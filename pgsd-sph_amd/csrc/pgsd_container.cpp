@@ -404,7 +404,8 @@ int expand_file_index(Impl* s, size_t size_required, int* local_rc)
 
     // The new block goes to the TRUE end of the file as rank 0 sees it
     // (MPI_File_get_size, pgsd.c:1015) once every rank's data is in the file.
-    s->n_collectives++;
+    if (s->P > 1) // (one rank: nothing is exchanged, nothing is counted -- like the allgathers)
+        s->n_collectives++;
     int brc = comm_barrier(s->comm);
     if (brc != PGSD_SUCCESS)
         return brc;
