@@ -1,5 +1,5 @@
 // pgsd_device_stub.cpp -- NOT part of libpgsd_amd.so.  Link-time stand-ins for the device
-// pipeline so that the HOST file layer (pgsd_file.cpp, pgsd_comm.cpp, pgsd_io.cpp) can be built
+// pipeline so that the HOST file layer (pgsd_container.cpp, pgsd_placement.cpp, pgsd_read.cpp, pgsd_comm.cpp, pgsd_io.cpp) can be built
 // with gcc -fsanitize=address,undefined and exercised by the scenario driver on a CPU box
 // (`make asan`; GPU AddressSanitizer is not available on the pool).  Every device entry point
 // fails with PGSD_ERROR_NO_DEVICE, exactly as the real library does without a GPU.

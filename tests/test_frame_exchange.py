@@ -13,7 +13,7 @@ from pgsd import _lib
 import pgsd.fl as fl
 
 
-FRAME_MESSAGE = 512     # bytes per rank of a frame exchange (64 words: status, count, 62 sizes), pgsd_file.cpp
+FRAME_MESSAGE = 512     # bytes per rank of a frame exchange (64 words: status, count, 62 sizes), pgsd_placement.cpp
 
 
 class MirrorComm:

@@ -31,7 +31,7 @@ def test_single_rank_batched_and_per_chunk(tmp_path):
 
 
 def test_single_rank_over_the_librarys_rccl_communicator(tmp_path):
-    """the C++ bootstrap: unique id -> pgsd_comm_init_rccl, every later exchange is an ncclAllGather"""
+    """the C++ bootstrap: unique id -> pgsd_comm_create_rccl + pgsd_comm_set_default, every later exchange is an ncclAllGather"""
     product.build()
     out = run([100000, 3, str(tmp_path / "rccl.gsd"), "batched", "rccl"], {"PGSD_RANK": "0", "PGSD_NRANKS": "1"})
     d = json.loads(out.strip().splitlines()[-1])

@@ -36,7 +36,7 @@ def _fake_logs(prefix, P):
 @pytest.mark.parametrize("P", [2, 3])
 def test_native_bootstrap_and_frame_exchange_over_the_rccl_back_end(P, tmp_path):
     """benchmark_write.hip ... rccl: rank 0's ncclUniqueId travels over the shm communicator of the launch, every
-    rank calls pgsd_comm_init_rccl, and from then on every exchange of the run is an ncclAllGather issued by
+    rank calls pgsd_comm_create_rccl + pgsd_comm_set_default, and from then on every exchange of the run is an ncclAllGather issued by
     pgsd_comm_rccl.cpp -- one per frame.  The file is then read back and verified by benchmark_read.hip."""
     product.build()
     assert os.path.exists(FAKE)
@@ -101,7 +101,7 @@ dist.destroy_process_group()
 @pytest.mark.parametrize("counts", [[900, 1201], [0, 4097, 1, 333]])
 def test_init_from_torch_builds_the_rccl_back_end_at_several_ranks(counts, tmp_path):
     """pgsd.dist.init_from_torch over a gloo group whose ranks share cuda:0: id from rank 0 by torch broadcast,
-    pgsd_comm_init_rccl on every rank, self-check exchange, agreement; then a batched device write whose only
+    pgsd_comm_create_rccl on every rank, self-check exchange, agreement; then a batched device write whose only
     collective per frame is the back end's allgather.  The file equals the oracle's P-rank file."""
     import scenario as S
     from test_gpu_file import _oracle_frames
