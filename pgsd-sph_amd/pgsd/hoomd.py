@@ -207,6 +207,33 @@ class ParticleData(object):
             raise ValueError("Type names must be unique.")
 
 
+class BondData(object):
+    """Topology container of the upstream schema (hoomd.py:273-362): ``M`` particles per group (2 bonds / pairs, 3
+    angles, 4 dihedrals / impropers), ``N``, ``types``, ``typeid`` (N,) uint32, ``group`` (N, M) int32.  The reference
+    keeps the class but no :class:`Frame` of it carries topology (``Frame.__init__``, hoomd.py:450-456; the sections
+    are commented out of its writer, hoomd.py:585-590), and neither does this one: the class is here so that code
+    written against the reference imports and validates the same way."""
+
+    def __init__(self, M):
+        self.M = M
+        self.N = 0
+        self.types = None
+        self.typeid = None
+        self.group = None
+        self._default_value = OrderedDict(
+            [('N', numpy.uint32(0)), ('types', []), ('typeid', numpy.uint32(0)),
+             ('group', numpy.array([0] * M, dtype=numpy.int32))])
+
+    def validate(self):
+        logger.debug('Validating BondData')
+        for name, dtype, shape in (('typeid', numpy.uint32, [self.N]), ('group', numpy.int32, [self.N, self.M])):
+            value = getattr(self, name)
+            if value is not None:
+                setattr(self, name, numpy.ascontiguousarray(value, dtype=dtype).reshape(shape))
+        if self.types is not None and len(set(self.types)) != len(self.types):
+            raise ValueError("Type names must be unique.")
+
+
 class ConstraintData(object):
     """Store constraint data (hoomd.py:365-421): ``N``, ``value`` (N,) float32, ``group`` (N, 2) int32."""
 

@@ -307,3 +307,26 @@ def test_elision_comparisons_agree_with_numpy():
     assert not H._equal(big, big[:-1])
     nan = numpy.array([numpy.nan], dtype=numpy.float32)
     assert not H._equal(nan, nan) and not H._equiv(nan, numpy.nan)      # array_equal's NaN semantics are kept
+
+
+def test_bond_data_is_importable_and_validates_like_the_reference():
+    """hoomd.py:273-362: the class exists in the reference although no Frame of it carries topology; code written
+    against the reference must import and validate it the same way."""
+    b = hoomd.BondData(3)
+    assert (b.M, b.N, b.types, b.typeid, b.group) == (3, 0, None, None, None)
+    assert list(b._default_value) == ['N', 'types', 'typeid', 'group'] and b._default_value['group'].shape == (3,)
+    b.N = 2
+    b.typeid = [0, 1]
+    b.group = [0, 1, 2, 1, 2, 3]
+    b.types = ['A', 'B']
+    b.validate()
+    assert b.typeid.dtype == np.uint32 and b.typeid.shape == (2,)
+    assert b.group.dtype == np.int32 and b.group.shape == (2, 3)
+    b.types = ['A', 'A']
+    with pytest.raises(ValueError, match="unique"):
+        b.validate()
+    b.types = ['A']
+    b.group = [0, 1, 2]                 # not N x M
+    with pytest.raises(ValueError):
+        b.validate()
+    assert not hasattr(hoomd.Frame(), "bonds")          # as in the reference (hoomd.py:450-456)
