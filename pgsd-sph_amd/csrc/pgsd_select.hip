@@ -2,8 +2,8 @@
 //   compare_bytes_kernel   packed chunk == reference rows?  (the GPU-side elision test of pgsd.hoomd: numpy's equality,
 //                          repeating references; reads only, 0.82-0.86 of the HBM peak)
 //   select_*_kernel        stream compaction for filtered snapshots: wave ballot / popcount scans give each workgroup's
-//                          count, a one-block scan turns counts into offsets (= per-chunk row and byte counts), a scatter
-//                          pass writes the index list (pgsd_select_rows)
+//                          count, a one-block scan turns counts into offsets (= per-chunk row and byte counts) and
+//                          hands the total to the host, a scatter pass writes the index list (pgsd_select_rows)
 //   pgsd_device_alloc / _free / _copy   device memory owned by the library (pgsd.fl.DeviceBuffer)
 // Shared device helpers: pgsd_kernels.hpp.
 #include "pgsd_kernels.hpp"
@@ -239,30 +239,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
     return x;
     }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_count_kernel(const uint8_t* flags, uint64_t N,
-                                                                   uint32_t* block_counts)
+// exclusive scan of the block counts by ONE workgroup; also writes the total -- to device memory and straight into the
+// caller's pinned word (a system-scope store: no copy command behind the kernels)
+__device__ __forceinline__ void select_scan_block(const uint32_t* block_counts, uint32_t n_blocks, uint64_t* block_offsets,
+                                                  uint64_t* out_count, uint64_t* out_count_host, uint32_t* wave_sums,
+                                                  uint64_t* carry)
     {
-    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
-    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
-    uint32_t mask;
-    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
-    uint32_t inc = wave_inclusive_scan(c);
-    if ((threadIdx.x & 63) == 63)
-        wave_sums[threadIdx.x >> 6] = inc;
-    __syncthreads();
     if (threadIdx.x == 0)
-        block_counts[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
-    }
-
-// exclusive scan of the block counts by ONE workgroup; also writes the total
-__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
-                                                                  uint64_t* block_offsets,
-                                                                  uint64_t* out_count)
-    {
-    __shared__ uint64_t carry;
-    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
-    if (threadIdx.x == 0)
-        carry = 0;
+        *carry = 0;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += SEL_THREADS)
         {
@@ -276,14 +260,43 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(uint32_t* bloc
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
             wave_off += wave_sums[w];
         if (i < n_blocks)
-            block_offsets[i] = carry + wave_off + inc - c;
+            block_offsets[i] = *carry + wave_off + inc - c;
         __syncthreads();
         if (threadIdx.x == SEL_THREADS - 1)
-            carry += (uint64_t)wave_off + inc;
+            *carry += (uint64_t)wave_off + inc;
         __syncthreads();
         }
     if (threadIdx.x == 0)
-        *out_count = carry;
+        {
+        *out_count = *carry;
+        __hip_atomic_store(out_count_host, *carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+
+__global__ __launch_bounds__(SEL_THREADS) void select_count_kernel(const uint8_t* flags, uint64_t N, uint32_t* block_counts)
+    {
+    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    uint64_t base = ((uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x) * SEL_PER_THREAD;
+    uint32_t mask;
+    uint32_t c = base < N ? sel_load16(flags, base, N, &mask) : 0;
+    uint32_t inc = wave_inclusive_scan(c);
+    if ((threadIdx.x & 63) == 63)
+        wave_sums[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    }
+
+// (A launch of its own: letting the LAST counting workgroup scan -- a ticket counter, release / acquire at device scope
+// in every workgroup -- was measured at 87-95 us per call against 37-44: on a part whose eight L2s are not coherent
+// with each other such fences write back and invalidate whole caches; profiles/r05_select_bench.jsonl.)
+__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(const uint32_t* block_counts, uint32_t n_blocks,
+                                                                  uint64_t* block_offsets, uint64_t* out_count,
+                                                                  uint64_t* out_count_host)
+    {
+    __shared__ uint32_t wave_sums[SEL_THREADS / 64];
+    __shared__ uint64_t carry;
+    select_scan_block(block_counts, n_blocks, block_offsets, out_count, out_count_host, wave_sums, &carry);
     }
 
 __global__ __launch_bounds__(SEL_THREADS) void select_scatter_kernel(const uint8_t* flags, uint64_t N,
@@ -343,7 +356,8 @@ struct SelectScratch
     {
     void* dev = nullptr;
     size_t cap = 0;
-    uint64_t* host_count = nullptr; // pinned
+    uint64_t* host_count = nullptr;     // pinned, device-mapped: the scan writes the count into it
+    uint64_t* host_count_dev = nullptr; // ... through this alias
     };
 std::mutex g_select_lock;
 std::map<int, SelectScratch> g_select_scratch;
@@ -401,15 +415,25 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
             const size_t cap = std::max<size_t>(need * 2, 1u << 16);
             if (hipMalloc(&sc.dev, cap) != hipSuccess)
                 {
+                sc.dev = nullptr;
                 set_last_error("pgsd_select_rows: cannot allocate the scratch space");
                 return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
                 }
             sc.cap = cap;
             }
-        if (!sc.host_count && hipHostMalloc((void**)&sc.host_count, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess)
+        if (!sc.host_count)
             {
-            set_last_error("pgsd_select_rows: cannot allocate pinned memory");
-            return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
+            void* alias = nullptr;
+            if (hipHostMalloc((void**)&sc.host_count, sizeof(uint64_t), hipHostMallocMapped) != hipSuccess
+                || hipHostGetDevicePointer(&alias, sc.host_count, 0) != hipSuccess)
+                {
+                if (sc.host_count)
+                    (void)hipHostFree(sc.host_count);
+                sc.host_count = nullptr;
+                set_last_error("pgsd_select_rows: cannot allocate pinned memory");
+                return PGSD_ERROR_MEMORY_ALLOCATION_FAILED;
+                }
+            sc.host_count_dev = (uint64_t*)alias;
             }
         }
     uint64_t* out_count = (uint64_t*)sc.dev;
@@ -422,7 +446,7 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
         hipLaunchKernelGGL(select_count_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags, N,
                            block_counts);
         hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, block_counts,
-                           (uint32_t)n_blocks, block_offsets, out_count);
+                           (uint32_t)n_blocks, block_offsets, out_count, sc.host_count_dev);
         hipLaunchKernelGGL(select_scatter_kernel, dim3((unsigned)n_blocks), dim3(SEL_THREADS), 0, stream, flags,
                            N, block_offsets, out_index);
         }
@@ -432,15 +456,13 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
         set_last_error(std::string("select kernel launch failed: ") + hipGetErrorString(e));
         return PGSD_ERROR_DEVICE;
         }
-    e = hipMemcpyAsync(sc.host_count, out_count, sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(stream);
+    e = hipStreamSynchronize(stream); // the kernels are through: the count is in the pinned word
     if (e != hipSuccess)
         {
         set_last_error(std::string("pgsd_select_rows: ") + hipGetErrorString(e));
         return PGSD_ERROR_DEVICE;
         }
-    *out_count_host = *sc.host_count;
+    *out_count_host = __atomic_load_n(sc.host_count, __ATOMIC_ACQUIRE);
     return PGSD_SUCCESS;
     }
 catch (...)

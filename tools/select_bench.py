@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the stream compaction (pgsd_select_rows: count, scan, scatter) on N flags.  Since round 5 the call returns the
-count in HOST memory (one device->host copy + one stream wait inside the call): the figures are the whole call, the three
+count in HOST memory (the scan kernel stores it into a pinned word; one stream wait inside the call): the figures are the whole call, the three
 kernels alone take 20-28 us at 10 M flags (profiles/r01_select_bench.jsonl)."""
 import ctypes
 import json
