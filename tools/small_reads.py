@@ -8,10 +8,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pgsd-sph_amd"))
-import numpy as np
 import torch
 import pgsd.hoomd as H
-import pgsd.fl as fl
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 path = "/dev/shm/pgsd_small_reads_%d.gsd" % os.getpid()
