@@ -93,6 +93,32 @@ def test_gpus_flag_launches_that_many_ranks():
     assert d["config"]["parallelism"] == "particle-partition x2"
 
 
+def test_under_torch_distributed_run_the_way_the_driver_starts_it():
+    """The driver's own command line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- with two ranks sharing the one GPU of the box:
+    rank 0 prints exactly ONE line on stdout, the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+    is what the ranks rendezvous on, and a WORLD_SIZE that disagrees with --gpus is refused by every rank."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    args = ["--steps", "3", "--warmup", "1", "--particles", "200000", "--traffic", "off", "--no-cpu-baseline",
+            "--rehearse-shared-gpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(launch + ["--gpus", "2"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["collectives_per_frame"] == 1.0 and d["config"]["parallelism"] == "particle-partition x2"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "legs" not in d          # legs: one rank only
+    p = subprocess.run(launch + ["--gpus", "4"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in p.stderr
+
+
 def test_single_rank_line_carries_the_exchange_probe():
     d = run_bench("--traffic", "off", "--no-cpu-baseline")
     assert d["exchange_us"] is None                 # one rank: no exchange
