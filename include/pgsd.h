@@ -1,6 +1,6 @@
 /* pgsd.h -- C ABI of the MI355X-native PGSD snapshot writer (libpgsd_amd.so).
  *
- * Part 1 is the drop-in boundary: the same sixteen entry points, enums and on-disk structs
+ * Part 1 is the drop-in boundary: the same eighteen entry points, enums and on-disk structs
  * as the reference's /root/reference/pgsd/pgsd/pgsd.h (each prototype cites the line it
  * replaces), so a caller of the reference (pgsd/pgsd/fl.pyx, pgsd/scripts/benchmark-write.cc,
  * HOOMD-SPH's dump writer) re-links without source changes.  Files written through it are
@@ -16,7 +16,8 @@
  *     rank; only rank 0 writes it.  pgsd_find_chunk() is therefore valid on every rank.
  *   - part 3 adds the device path: chunks are packed from HBM-resident particle arrays
  *     by HIP kernels, streamed to pinned host slabs with hipMemcpyAsync and written with
- *     pwrite at the offsets the reference's MPI_File_write_at would use.
+ *     pwrite at the offsets the reference's MPI_File_write_at would use -- or, with PGSD_IO=mpiio
+ *     in the environment, by MPI_File_write_at itself (plugin libpgsd_amd_mpiio.so).
  */
 #ifndef PGSD_H
 #define PGSD_H
