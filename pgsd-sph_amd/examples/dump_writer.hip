@@ -224,9 +224,23 @@ int main(int argc, char** argv)
     std::vector<uint64_t> frame_kept; // this rank's rows in every frame
     unsigned long long chunks_written = 0, chunks_elided = 0;
 
+    // DUMP_WRITER_TIMING=1: where the host spends a snapshot call, per frame, on stderr
+    const bool lap_on = getenv("DUMP_WRITER_TIMING") != NULL;
     auto snapshot = [&](uint64_t step) -> int
     {
         const auto t0 = std::chrono::steady_clock::now();
+        auto lap_t = t0;
+        char laps[400] = "";
+        size_t lap_at = 0;
+        auto lap = [&](const char* what)
+        {
+            if (!lap_on)
+                return;
+            const auto t = std::chrono::steady_clock::now();
+            lap_at += (size_t)snprintf(laps + lap_at, sizeof(laps) - lap_at, " %s %.0f", what,
+                                       std::chrono::duration<double, std::micro>(t - lap_t).count());
+            lap_t = t;
+        };
         // which rows, in which order: the group's tags ascending, each looked up in the reverse-tag array
         uint64_t kept = n;
         const uint32_t* gather = rtag;
@@ -239,9 +253,11 @@ int main(int argc, char** argv)
             }
         for (int i = 0; i < N_CHUNKS; i++)
             req[i].src.order = gather;
+        lap("select");
         const uint32_t frame = (uint32_t)frame_step.size();
         uint64_t ticket = 0;
         CHECK(pgsd_stage_chunks_device(&h, N_CHUNKS, req, kept, &ticket)); // ONE fused gather + pack launch
+        lap("stage");
         Vote mine;
         memset(&mine, 0, sizeof(mine));
         mine.kept = kept;
@@ -255,6 +271,7 @@ int main(int argc, char** argv)
             }
         else if (kept == frame0_kept)
             CHECK(pgsd_compare_staged_chunks(&h, ticket, 0, N_CHUNKS, frame0_rows, NULL, mine.same));
+        lap("compare");
         // THE collective of the frame: every rank's row count and its "unchanged since frame 0" votes travel together;
         // the counts are then DECLARED (pgsd_set_partition), so placing the chunks needs no exchange of its own
         std::vector<Vote> votes((size_t)P);
@@ -280,8 +297,13 @@ int main(int argc, char** argv)
                 chunks_written++;
                 }
             }
+        lap("place");
         CHECK(pgsd_end_frame_async(&h));    // the frame is sealed; its bytes follow in the background
+        lap("seal");
         CHECK(pgsd_device_wait_packed(&h)); // ... and the arrays are the simulation's again
+        lap("wait_packed");
+        if (lap_on)
+            fprintf(stderr, "frame %u:%s us\n", frame, laps);
         stall_us.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6);
         frame_step.push_back(step);
         frame_kept.push_back(kept);
