@@ -501,7 +501,11 @@ extern "C"
         uint32_t n_slabs;       /* slabs in the ring (default 16) */
         uint32_t n_writers;     /* pwrite threads (default 1: one file = one inode lock) */
         uint32_t profile;       /* 1 = bracket every pack launch with HIP events */
-        uint32_t reserved;
+        uint32_t prealloc_mib;  /* 0: staging blocks (256 MiB of HBM each) and ring slabs are allocated when a frame first
+                                   needs them and kept until close.  > 0: this call allocates that much staging (rounded up to
+                                   whole blocks) and the WHOLE ring, so that no snapshot of the run meets an allocation: a
+                                   hipMalloc / hipHostMalloc in the middle of a run costs 0.03 ... 38 ms depending on the
+                                   box's state and stalls streams it has nothing to do with */
         };
     int pgsd_device_configure(struct pgsd_handle* handle, const struct pgsd_device_config* cfg);
 

@@ -345,7 +345,9 @@ class DevicePipeline
                 (void)hipHostFree(ps.first);
                 }
             }
-        if (m_slabs_ready < std::min<uint32_t>(m_cfg.n_slabs, 2))
+        // prealloc_mib: the whole ring and that much staging now, nothing in the middle of the run
+        const uint32_t first_slabs = m_cfg.prealloc_mib ? m_cfg.n_slabs : std::min<uint32_t>(m_cfg.n_slabs, 2);
+        if (m_slabs_ready < first_slabs)
             {
             hipError_t alloc_err = hipSuccess;
             std::thread allocator(
@@ -357,7 +359,7 @@ class DevicePipeline
                     (void)hipSetDevice(m_cfg.device);
                     // two slabs now; the dispatcher (pinned to the same node) adds the rest of the ring
                     // when a frame actually needs them, so a small file never pins 256 MiB
-                    while (m_slabs_ready < m_cfg.n_slabs && m_slabs_ready < 2)
+                    while (m_slabs_ready < first_slabs)
                         {
                         hipError_t e = alloc_slab(m_slabs[m_slabs_ready]);
                         if (e != hipSuccess)
@@ -373,6 +375,25 @@ class DevicePipeline
             }
         for (uint32_t i = 0; i < m_slabs_ready; i++)
             m_free_slabs.push_back(i);
+        size_t staged_cap = 0;
+        for (auto& a : m_arenas)
+            staged_cap += a.cap;
+        if (m_cfg.prealloc_mib)
+            {
+            int brc = compare_buffers();
+            if (brc != PGSD_SUCCESS)
+                return brc;
+            }
+        while (staged_cap < ((size_t)m_cfg.prealloc_mib << 20))
+            {
+            Arena a;
+            a.base = nullptr;
+            a.cap = (size_t)256 << 20;
+            a.used = 0;
+            HIP_TRY(hipMalloc((void**)&a.base, a.cap));
+            m_arenas.push_back(a);
+            staged_cap += a.cap;
+            }
         const cpu_set_t* pin = m_numa ? &m_numa_cpus : nullptr;
         m_pool = writer_pool_create(m_cfg.n_writers, pin);
         m_dispatcher = std::thread([this] { dispatch_loop(); });
@@ -736,34 +757,9 @@ class DevicePipeline
         int orc = order_after_source();
         if (orc != PGSD_SUCCESS)
             return orc;
-        // (each step on its own: a call that failed half-way is picked up where it stopped by the next one)
-        if (!m_cmp_host)
-            {
-            void* h = nullptr;
-            HIP_TRY(hipHostMalloc(&h, CMP_MAX_JOBS * sizeof(uint32_t), hipHostMallocMapped));
-            memset(h, 0, CMP_MAX_JOBS * sizeof(uint32_t));
-            m_cmp_host = (uint32_t*)h;
-            }
-        if (!m_cmp_host_dev)
-            {
-            void* hd = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&hd, m_cmp_host, 0));
-            m_cmp_host_dev = (uint32_t*)hd;
-            }
-        if (!m_cmp_dev)
-            {
-            void* d = nullptr;
-            HIP_TRY(hipMalloc(&d, CMP_MAX_JOBS * sizeof(uint32_t)));
-            // on the stream the kernels run on: a null-stream memset is not ordered with a non-blocking stream
-            hipError_t me = hipMemsetAsync(d, 0, CMP_MAX_JOBS * sizeof(uint32_t), m_pack_stream);
-            if (me != hipSuccess)
-                {
-                (void)hipFree(d);
-                fail(std::string("hipMemsetAsync: ") + hipGetErrorString(me));
-                return PGSD_ERROR_DEVICE;
-                }
-            m_cmp_dev = (uint32_t*)d;
-            }
+        int brc = compare_buffers();
+        if (brc != PGSD_SUCCESS)
+            return brc;
         for (size_t at = 0; at < jobs.size(); at += CMP_MAX_JOBS)
             {
             const uint32_t n = (uint32_t)std::min<size_t>(CMP_MAX_JOBS, jobs.size() - at);
@@ -1304,6 +1300,41 @@ class DevicePipeline
             (timing ? m_misc_timing_events : m_misc_events).push_back(ev);
             }
         return ev;
+        }
+
+    // the answer words of compare(): pinned and device-mapped, plus the early-exit words in HBM.  Made by the first
+    // comparison -- or by init() when the caller asked for everything up front (prealloc_mib)
+    int compare_buffers()
+        {
+        // (each step on its own: a call that failed half-way is picked up where it stopped by the next one)
+        if (!m_cmp_host)
+            {
+            void* h = nullptr;
+            HIP_TRY(hipHostMalloc(&h, CMP_MAX_JOBS * sizeof(uint32_t), hipHostMallocMapped));
+            memset(h, 0, CMP_MAX_JOBS * sizeof(uint32_t));
+            m_cmp_host = (uint32_t*)h;
+            }
+        if (!m_cmp_host_dev)
+            {
+            void* hd = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&hd, m_cmp_host, 0));
+            m_cmp_host_dev = (uint32_t*)hd;
+            }
+        if (!m_cmp_dev)
+            {
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, CMP_MAX_JOBS * sizeof(uint32_t)));
+            // on the stream the kernels run on: a null-stream memset is not ordered with a non-blocking stream
+            hipError_t me = hipMemsetAsync(d, 0, CMP_MAX_JOBS * sizeof(uint32_t), m_pack_stream);
+            if (me != hipSuccess)
+                {
+                (void)hipFree(d);
+                fail(std::string("hipMemsetAsync: ") + hipGetErrorString(me));
+                return PGSD_ERROR_DEVICE;
+                }
+            m_cmp_dev = (uint32_t*)d;
+            }
+        return PGSD_SUCCESS;
         }
 
     int arena_alloc(size_t bytes, void** out)

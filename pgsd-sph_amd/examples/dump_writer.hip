@@ -24,6 +24,8 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include dump_writer.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
 //   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./dump_writer [particles_per_rank] [steps] [period] [file] [all|fluid] [keep]
+//   DUMP_WRITER_PREALLOC_MIB=n: pgsd_device_configure(prealloc_mib = n) -- no allocation meets a snapshot;
+//   DUMP_WRITER_TIMING=1: where the host spends each snapshot call (stderr)
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
@@ -205,6 +207,14 @@ int main(int argc, char** argv)
     // ---- the file
     struct pgsd_handle h;
     CHECK(pgsd_create_and_open(&h, path, "dump_writer", "hoomd", pgsd_make_version(1, 4), PGSD_OPEN_READWRITE, 0));
+    if (const char* mib = getenv("DUMP_WRITER_PREALLOC_MIB")) // staging and the whole pinned ring now, nothing during the run
+        {
+        struct pgsd_device_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.device = rank % ndev;
+        cfg.prealloc_mib = (uint32_t)atoi(mib);
+        CHECK(pgsd_device_configure(&h, &cfg));
+        }
     CHECK(pgsd_set_frame_exchange(&h, 1));          // one allgather per frame places every chunk
     CHECK(pgsd_device_set_source_stream(&h, sim));  // the pack waits for the simulation's kernels, not the host
     enum { POSITION, TYPEID, VELOCITY, MASS, DENSITY, N_CHUNKS };

@@ -1151,8 +1151,10 @@ cdef class PGSDFile:
             retval = C.pgsd_device_wait_packed(&self._handle)
         _raise_on_error(retval, self._name)
 
-    def configure_device(self, device=-1, slab_bytes=0, n_slabs=0, n_writers=0, profile=False):
-        """(Re)create the device pipeline of this file with explicit staging parameters."""
+    def configure_device(self, device=-1, slab_bytes=0, n_slabs=0, n_writers=0, profile=False, prealloc_mib=0):
+        """(Re)create the device pipeline of this file with explicit staging parameters.  ``prealloc_mib`` > 0: that
+        much HBM staging and the whole ring of pinned slabs are allocated by this call instead of when a frame first
+        needs them -- a simulation pays for its allocations before the run, not during a snapshot."""
         cdef C.pgsd_device_config cfg
         cdef int retval
         self._check_open()
@@ -1162,6 +1164,7 @@ cdef class PGSDFile:
         cfg.n_slabs = n_slabs
         cfg.n_writers = n_writers
         cfg.profile = 1 if profile else 0
+        cfg.prealloc_mib = prealloc_mib
         with nogil:
             retval = C.pgsd_device_configure(&self._handle, &cfg)
         _raise_on_error(retval, self._name)

@@ -107,7 +107,7 @@ class UnpackJob(ctypes.Structure):
 
 class DeviceConfig(ctypes.Structure):
     _fields_ = [("device", c_i32), ("slab_bytes", c_u64), ("n_slabs", c_u32), ("n_writers", c_u32),
-                ("profile", c_u32), ("reserved", c_u32)]
+                ("profile", c_u32), ("prealloc_mib", c_u32)]
 
 
 class DeviceStats(ctypes.Structure):

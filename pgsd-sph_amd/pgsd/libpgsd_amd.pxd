@@ -155,7 +155,7 @@ cdef extern from "pgsd.h" nogil:
         uint32_t n_slabs
         uint32_t n_writers
         uint32_t profile
-        uint32_t reserved
+        uint32_t prealloc_mib
 
     cdef struct pgsd_device_stats:
         uint64_t pack_launches
