@@ -1,7 +1,8 @@
 // dump_writer.hip -- what a GPU simulation's snapshot writer looks like on top of libpgsd_amd.so (C ABI only).
 //
 // A toy "simulation" advances HOOMD-style Scalar4 arrays in HBM on a stream of its own, one kernel per step.  Its
-// particles sit in MEMORY order (the order a space-filling-curve sorter leaves them in), the file wants them in TAG
+// particles sit in MEMORY order (along a Hilbert curve through their lattice sites: the order a space-filling-curve
+// sorter leaves them in; or, "random", in an adversarial uniform-like order), the file wants them in TAG
 // order, and optionally only a group of them (everything that is not a wall particle).  Every `period` steps the
 // writer takes a snapshot the way HOOMD-SPH's dump writer would, without leaving the GPU:
 //
@@ -23,12 +24,13 @@
 // step before a snapshot and the first one after) next to a step's time.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include dump_writer.hip -L pgsd-sph_amd/pgsd -lpgsd_amd
-//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./dump_writer [particles_per_rank] [steps] [period] [file] [all|fluid] [keep]
+//   PGSD_RANK=r PGSD_NRANKS=P PGSD_SHM_NAME=job ./dump_writer [particles_per_rank] [steps] [period] [file] [all|fluid] [keep|-] [hilbert|random]
 //   DUMP_WRITER_PREALLOC_MIB=n: pgsd_device_configure(prealloc_mib = n) -- no allocation meets a snapshot;
 //   DUMP_WRITER_TIMING=1: where the host spends each snapshot call (stderr)
 #include "pgsd.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -63,20 +65,65 @@ __host__ __device__ inline float density_at(uint64_t g, uint64_t step)
     return 1000.f + 0.5f * (float)step + (float)(g % 7);
     }
 
-// slot s of the rank's arrays holds local tag (s * a + b) % n: a bijection because gcd(a, n) == 1
-__global__ void init_kernel(float4* pos, float4* vel, float* density, uint32_t* tag, uint32_t* rtag, uint64_t n, uint64_t a,
-                            uint64_t b, uint64_t row0)
+// ---- memory order.  "random": slot s holds local tag (s * a + b) % n (a bijection because gcd(a, n) == 1) -- every
+// gathered row a DRAM sector of its own, the adversarial case.  "hilbert": particles are created in lattice order (tag t at
+// site (t % m, t / m % m, t / m^2), m = ceil(cbrt n)) and kept in memory along the 3-D Hilbert curve through their sites
+// (Skilling's transform, AIP Conf. Proc. 707, 2004) -- what a space-filling-curve sorter leaves a dump writer with.
+__global__ void order_random_kernel(uint32_t* tag, uint64_t n, uint64_t a, uint64_t b)
+    {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n)
+        tag[s] = (uint32_t)((s * a + b) % n);
+    }
+
+__global__ void hilbert_key_kernel(uint64_t* key, uint32_t* tags, uint64_t n, uint32_t m, int bits)
+    {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    uint32_t X[3] = {(uint32_t)(t % m), (uint32_t)(t / m % m), (uint32_t)(t / ((uint64_t)m * m))};
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) // inverse undo
+        {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < 3; i++)
+            if (X[i] & Q)
+                X[0] ^= P;
+            else
+                {
+                const uint32_t tt = (X[0] ^ X[i]) & P;
+                X[0] ^= tt;
+                X[i] ^= tt;
+                }
+        }
+    X[1] ^= X[0]; // Gray encode
+    X[2] ^= X[1];
+    uint32_t tt = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q)
+            tt ^= Q - 1;
+    for (int i = 0; i < 3; i++)
+        X[i] ^= tt;
+    uint64_t k = 0;
+    for (int bit = bits - 1; bit >= 0; bit--)
+        for (int i = 0; i < 3; i++)
+            k = (k << 1) | ((X[i] >> bit) & 1u);
+    key[t] = k;
+    tags[t] = (uint32_t)t;
+    }
+
+// slot s holds local tag tag[s]: the particle's state, and the reverse tag
+__global__ void init_kernel(float4* pos, float4* vel, float* density, const uint32_t* tag, uint32_t* rtag, uint64_t n, uint64_t row0)
     {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n)
         return;
-    const uint64_t t = (s * a + b) % n, g = row0 + t;
+    const uint64_t t = tag[s], g = row0 + t;
     float p[3], v[4];
     initial_row(g, p, v);
     pos[s] = make_float4(p[0], p[1], p[2], __uint_as_float(type_of(g)));
     vel[s] = make_float4(v[0], v[1], v[2], v[3]);
     density[s] = density_at(g, 0);
-    tag[s] = (uint32_t)t;
     rtag[t] = (uint32_t)s;
     }
 
@@ -163,9 +210,10 @@ int main(int argc, char** argv)
     const char* path = argc > 4 ? argv[4] : "/dev/shm/pgsd_dump_writer.gsd";
     const bool fluid_only = argc > 5 && strcmp(argv[5], "fluid") == 0;
     const bool keep = argc > 6 && strcmp(argv[6], "keep") == 0;
-    if (n == 0 || n >= (1ull << 32))
+    const bool hilbert = !(argc > 7 && strcmp(argv[7], "random") == 0);
+    if (n == 0 || n >= (1ull << 31))
         {
-        fprintf(stderr, "particles_per_rank must be in [1, 2^32)\n");
+        fprintf(stderr, "particles_per_rank must be in [1, 2^31)\n");
         return 1;
         }
     CHECK(pgsd_comm_init_from_env());
@@ -195,13 +243,41 @@ int main(int argc, char** argv)
     HIP(hipMalloc((void**)&kept_tags, n * sizeof(uint32_t)));
     HIP(hipMalloc((void**)&order, n * sizeof(uint32_t)));
     HIP(hipMalloc((void**)&flags, n));
-    uint64_t a = 2654435761ull % n;
-    while (a < 2 ? n > 2 : gcd64(a, n) != 1)
-        a = a < 2 ? 2 : a + 1;
-    if (n <= 2)
-        a = 1;
-    const uint64_t b = n / 3;
-    hipLaunchKernelGGL(init_kernel, dim3(blocks_for(n)), dim3(256), 0, sim, pos, vel, density, tag, rtag, n, a, b, row0);
+    if (hilbert)
+        {
+        uint32_t m = 1;
+        while ((uint64_t)m * m * m < n)
+            m++;
+        int bits = 1;
+        while ((1u << bits) < m)
+            bits++;
+        uint64_t *key, *key_sorted;
+        uint32_t* tag_in;
+        HIP(hipMalloc((void**)&key, n * sizeof(uint64_t)));
+        HIP(hipMalloc((void**)&key_sorted, n * sizeof(uint64_t)));
+        HIP(hipMalloc((void**)&tag_in, n * sizeof(uint32_t)));
+        hipLaunchKernelGGL(hilbert_key_kernel, dim3(blocks_for(n)), dim3(256), 0, sim, key, tag_in, n, m, bits);
+        void* temp = NULL;
+        size_t temp_bytes = 0; // memory row i holds the tag with the i-th smallest key
+        HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key, key_sorted, tag_in, tag, (int)n, 0, 3 * bits, sim));
+        HIP(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+        HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key, key_sorted, tag_in, tag, (int)n, 0, 3 * bits, sim));
+        HIP(hipStreamSynchronize(sim));
+        (void)hipFree(temp);
+        (void)hipFree(key);
+        (void)hipFree(key_sorted);
+        (void)hipFree(tag_in);
+        }
+    else
+        {
+        uint64_t a = 2654435761ull % n;
+        while (a < 2 ? n > 2 : gcd64(a, n) != 1)
+            a = a < 2 ? 2 : a + 1;
+        if (n <= 2)
+            a = 1;
+        hipLaunchKernelGGL(order_random_kernel, dim3(blocks_for(n)), dim3(256), 0, sim, tag, n, a, n / 3);
+        }
+    hipLaunchKernelGGL(init_kernel, dim3(blocks_for(n)), dim3(256), 0, sim, pos, vel, density, tag, rtag, n, row0);
     HIP(hipGetLastError());
 
     // ---- the file
@@ -472,7 +548,7 @@ int main(int argc, char** argv)
         for (size_t i = 0, at = 0; i < gap_us.size() && i < 24 && at < sizeof(gaps) - 16; i++)
             at += (size_t)snprintf(gaps + at, sizeof(gaps) - at, "%s%.0f", i ? ", " : "", gap_us[i]);
         std::sort(gap_us.begin(), gap_us.end());
-        printf("{\"example\": \"dump_writer\", \"ranks\": %d, \"particles_per_rank\": %llu, \"group\": \"%s\", "
+        printf("{\"example\": \"dump_writer\", \"ranks\": %d, \"particles_per_rank\": %llu, \"group\": \"%s\", \"memory_order\": \"%s\", "
                "\"rows_per_frame_rank0\": %llu, \"steps\": %d, \"period\": %d, \"frames\": %llu, "
                "\"position_rows_modelled\": \"every %llu-th\", \"sim_gap_us_first_frames\": [%s], "
                "\"step_us\": %.1f, \"sim_gap_us_median\": %.1f, \"sim_gap_us_max\": %.1f, \"snapshot_call_us_median\": %.1f, "
@@ -480,7 +556,8 @@ int main(int argc, char** argv)
                "\"drained_after_s\": %.4f, \"pack_launches\": %llu, \"written_bytes_rank0\": %llu, "
                "\"collectives_rank0\": %llu, \"chunks_written\": %llu, \"chunks_elided\": %llu, "
                "\"verified_frames\": %llu, \"ok\": %s, \"failed_check\": %d}\n",
-               P, (unsigned long long)n, fluid_only ? "fluid" : "all", (unsigned long long)my_tags.size(), steps, period,
+               P, (unsigned long long)n, fluid_only ? "fluid" : "all",
+               hilbert ? "Hilbert curve x lattice tags" : "multiplicative permutation (uniform-like)", (unsigned long long)my_tags.size(), steps, period,
                (unsigned long long)n_frames, (unsigned long long)stride, gaps, step_ms_n ? step_ms_sum / step_ms_n * 1e3 : 0.0,
                gap_us.empty() ? 0.0 : gap_us[gap_us.size() / 2], gap_us.empty() ? 0.0 : gap_us.back(),
                s.empty() ? 0.0 : s[s.size() / 2], s.empty() ? 0.0 : s.back(), run_s, drained_s, (unsigned long long)st.pack_launches,

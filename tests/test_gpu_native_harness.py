@@ -131,10 +131,12 @@ def test_elide_harness_writes_only_what_differs_from_frame_0(tmp_path, writers):
 DUMP_EXE = os.path.join(product.CSRC, "build", "dump_writer")
 
 
-@pytest.mark.parametrize("ranks,group", [(1, "all"), (1, "fluid"), (2, "fluid"), (3, "all")])
-def test_dump_writer_under_a_running_simulation(tmp_path, ranks, group):
+@pytest.mark.parametrize("ranks,group,order", [(1, "all", "hilbert"), (1, "fluid", "hilbert"), (2, "fluid", "random"),
+                                               (3, "all", "hilbert"), (1, "all", "random")])
+def test_dump_writer_under_a_running_simulation(tmp_path, ranks, group, order):
     """examples/dump_writer.hip: a simulation stepping Scalar4 arrays on its own stream, snapshots gathered into tag
-    order through the reverse-tag array (optionally a group only: pgsd_select_rows), static arrays elided against
+    order through the reverse-tag array (memory order: a Hilbert curve through the lattice of tags, or an adversarial
+    uniform-like permutation; optionally a group only: pgsd_select_rows), static arrays elided against
     frame 0 in HBM, ONE collective per frame, asynchronous seals.  The program re-reads its file through the
     reference's entry points and compares every frame with a host model bit for bit (its exit code and `ok`); here
     the file is read once more through pgsd.fl and the group's size and the elision are checked from outside."""
@@ -143,7 +145,8 @@ def test_dump_writer_under_a_running_simulation(tmp_path, ranks, group):
     product.build()
     path = str(tmp_path / "dump.gsd")
     per_rank, steps, period = 50021, 40, 10
-    d = _run_ranks(DUMP_EXE, [per_rank, steps, period, path, group, "keep"], ranks)
+    d = _run_ranks(DUMP_EXE, [per_rank, steps, period, path, group, "keep", order], ranks)
+    assert d["memory_order"].startswith("Hilbert" if order == "hilbert" else "multiplicative")
     frames = steps // period + 1
     assert d["ok"] is True and d["failed_check"] == 0 and d["ranks"] == ranks and d["frames"] == frames == d["verified_frames"]
     assert d["pack_launches"] == frames                                  # one fused gather + pack launch per snapshot
