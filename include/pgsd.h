@@ -483,9 +483,10 @@ extern "C"
        What a simulation waits for per snapshot is then only the pack kernels
        (pgsd_device_wait_packed), not the file.  The frame's bytes are in the file after
        pgsd_frame_sync(), or after the next pgsd_end_frame / pgsd_flush / pgsd_close /
-       pgsd_find_chunk / pgsd_read_chunk on this handle.  When the on-disk index has to be
-       relocated (every few hundred chunks) the call degrades to the synchronous pgsd_end_frame.
-       The file layout is identical either way.  Collective like pgsd_end_frame. */
+       pgsd_find_chunk / pgsd_read_chunk on this handle.  Also when the on-disk index has to be
+       relocated (every few hundred chunks): where the file will end is known from the ranks' own
+       placements, no byte has to be waited for (until round 5 the call fell back to the synchronous
+       pgsd_end_frame there).  The file layout is identical either way.  Collective like pgsd_end_frame. */
     int pgsd_end_frame_async(struct pgsd_handle* handle);
     /* Wait until the device chunks of all asynchronously sealed frames of THIS rank are in the file. */
     int pgsd_frame_sync(struct pgsd_handle* handle);

@@ -189,6 +189,7 @@ int initialize_handle(Impl* s)
     s->file_size = io_file_size(s->fd);
     if (s->file_size < 0)
         return PGSD_ERROR_IO;
+    s->placed_end = s->file_size; // nothing of this handle is on its way yet
 
     // pgsd.c:1558-1562; the products are formed so that a damaged header cannot wrap them around
     if (s->header.namelist_location > (uint64_t)s->file_size
@@ -306,6 +307,7 @@ Impl* new_impl(const pgsd_comm* on)
 // drain, on every rank at the next flush)
 int meta_pwrite(Impl* s, const void* buf, size_t n, long long offset)
     {
+    s->note_placed(offset, n);
     if (s->meta_async && s->dev)
         {
         device_pipeline_write_host(s->dev, buf, n, offset);
@@ -394,6 +396,12 @@ int flush_write_buffer(Impl* s)
     return rc;
     }
 
+static bool check_eof_mode()
+    {
+    static const bool on = getenv("PGSD_CHECK_EOF") != nullptr;
+    return on;
+    }
+
 // pgsd_expand_file_index, pgsd.c:965-1091
 int expand_file_index(Impl* s, size_t size_required, int* local_rc)
     {
@@ -402,60 +410,67 @@ int expand_file_index(Impl* s, size_t size_required, int* local_rc)
     while (size_new <= size_required)
         size_new *= 2;
 
-    // The new block goes to the TRUE end of the file as rank 0 sees it
-    // (MPI_File_get_size, pgsd.c:1015) once every rank's data is in the file.
-    if (s->P > 1) // (one rank: nothing is exchanged, nothing is counted -- like the allgathers)
-        s->n_collectives++;
-    int brc = comm_barrier(s->comm);
-    if (brc != PGSD_SUCCESS)
-        return brc;
-    uint64_t eof = 0;
-    if (s->rank == 0)
-        {
-        const long long size = io_file_size(s->fd); // the true EOF (MPI_File_get_size, pgsd.c:1015)
-        if (size < 0)
-            *local_rc = PGSD_ERROR_IO;
-        eof = size < 0 ? 0 : (uint64_t)size;
-        }
+    // The new block goes to the TRUE end of the file (MPI_File_get_size, pgsd.c:1015, once every rank's data is in the
+    // file).  Where that end will be is known without waiting for the data: every rank has kept the end of the furthest
+    // byte it has written or handed to its pipeline (Impl::placed_end), and the largest of them IS the file's size once
+    // everything has landed.  One allgather; no barrier, no drain: a frame sealed asynchronously stays asynchronous when
+    // the index moves (until round 5 the seal fell back to the synchronous one here -- a 90 ms hiccup for a simulation
+    // with a backlog, examples/dump_writer.hip).
     std::vector<uint64_t> all;
-    int rc = s->allgather_u64(eof, all);
+    int rc = s->allgather_u64((uint64_t)s->placed_end, all);
     if (rc != PGSD_SUCCESS)
         return rc;
-    long long new_loc = (long long)all[0];
+    uint64_t eof = 0;
+    for (uint64_t e : all)
+        eof = std::max(eof, e);
+    long long new_loc = (long long)eof;
     long long old_loc = (long long)s->header.index_location;
     size_t old_bytes = size_old * sizeof(pgsd_index_entry);
     size_t new_bytes = size_new * sizeof(pgsd_index_entry);
 
+    // PGSD_CHECK_EOF (tests): the old way beside the new one.  do_flush has drained every rank's pipeline (it keeps the
+    // synchronous fall-back in this mode), so rank 0's fstat is the reference's MPI_File_get_size, and the old block can
+    // be read back and compared with the in-memory mirror that is copied below in its place.
+    if (check_eof_mode())
+        {
+        // (the allgather above was the point every rank reached with its writes done; the others wait in the barrier
+        // below while rank 0 looks)
+        if (s->rank == 0)
+            {
+            const long long size = io_file_size(s->fd);
+            std::vector<char> on_disk(old_bytes, 0);
+            pread_some(s->fd, on_disk.data(), old_bytes, old_loc);
+            if (size != new_loc || memcmp(on_disk.data(), s->file_index.data(), old_bytes) != 0)
+                {
+                set_last_error("PGSD_CHECK_EOF: index relocation: computed end of file " + std::to_string(new_loc)
+                               + ", fstat " + std::to_string(size)
+                               + (memcmp(on_disk.data(), s->file_index.data(), old_bytes) != 0 ? "; the index mirror differs from the block on disk" : ""));
+                fprintf(stderr, "%s\n", last_error());
+                *local_rc = PGSD_ERROR_FILE_CORRUPT;
+                }
+            }
+        if (s->P > 1)
+            s->n_collectives++;
+        int brc = comm_barrier(s->comm);
+        if (brc != PGSD_SUCCESS)
+            return brc;
+        }
+
     if (s->rank == 0)
         {
-        // copy the old block in pieces, then zero-fill (pgsd.c:1021-1062)
-        size_t piece = INDEX_COPY_ENTRIES * sizeof(pgsd_index_entry);
-        if (piece > old_bytes)
-            piece = old_bytes;
-        std::vector<char> buf(piece);
-        size_t done = 0;
-        while (done < old_bytes)
-            {
-            size_t n = old_bytes - done < piece ? old_bytes - done : piece;
-            pread_some(s->fd, buf.data(), n, old_loc + (long long)done);
-            if (pwrite_full(s->fd, buf.data(), n, new_loc + (long long)done) != 0)
-                *local_rc = PGSD_ERROR_IO;
-            done += n;
-            }
-        std::fill(buf.begin(), buf.end(), 0);
-        while (done < new_bytes)
-            {
-            size_t n = new_bytes - done < piece ? new_bytes - done : piece;
-            if (pwrite_full(s->fd, buf.data(), n, new_loc + (long long)done) != 0)
-                *local_rc = PGSD_ERROR_IO;
-            done += n;
-            }
+        // the old block -- its in-memory mirror: entries of asynchronously sealed frames may still be on their way to
+        // the file -- then zeros (pgsd.c:1021-1062 copies through the file)
+        std::vector<char> block(new_bytes, 0);
+        memcpy(block.data(), s->file_index.data(), old_bytes);
+        if (meta_pwrite(s, block.data(), new_bytes, new_loc) != 0)
+            *local_rc = PGSD_ERROR_IO;
         }
     s->header.index_location = (uint64_t)new_loc;
     s->file_size = new_loc + (long long)new_bytes;
     s->header.index_allocated_entries = size_new;
+    s->note_placed(new_loc, new_bytes); // (every rank: the block is part of the file whoever writes it)
     if (s->rank == 0)
-        if (pwrite_full(s->fd, &s->header, sizeof(s->header), 0) != 0)
+        if (meta_pwrite(s, &s->header, sizeof(s->header), 0) != 0)
             *local_rc = PGSD_ERROR_IO;
 
     // the in-memory mirror is the old block plus zeros; its used size is found the way
@@ -487,9 +502,10 @@ int do_flush(Impl* s, bool async, bool sync_point)
         return qrc;
 
     // Asynchronous sealing commits the metadata now and lets the device chunks finish in
-    // the background -- unless the on-disk index must move, which needs the file's true end
-    // and therefore every byte of every rank in place (decided alike on all ranks).
-    if (async && s->pending <= s->frame_index.size())
+    // the background -- also when the on-disk index must move: the file's true end is known
+    // from the ranks' placements (expand_file_index).  Only the PGSD_CHECK_EOF mode of the
+    // tests keeps the old synchronous fall-back, to compare that end with fstat's.
+    if (async && check_eof_mode() && s->pending <= s->frame_index.size())
         {
         uint64_t will_write = s->frame_index.size() + s->buffer_index.size() - s->pending;
         if (s->file_index_size + will_write > s->file_index.size())

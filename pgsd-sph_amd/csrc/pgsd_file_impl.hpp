@@ -201,6 +201,17 @@ struct Impl
         return rc;
         }
 
+    // The end of the file as it WILL be once everything this rank has written -- or handed to its pipeline to be
+    // written -- is in place: the largest offset + size of any write this handle issued, starting from the file's size
+    // at open.  The maximum over the ranks is what MPI_File_get_size returns after all of them have finished
+    // (pgsd.c:1015), known without waiting for a byte: pgsd_expand_file_index needs no drain (round 5).
+    long long placed_end = 0;
+    void note_placed(long long offset, uint64_t bytes)
+        {
+        if (bytes > 0 && offset >= 0 && offset + (long long)bytes > placed_end)
+            placed_end = offset + (long long)bytes;
+        }
+
     int allgather_u64(uint64_t v, std::vector<uint64_t>& out)
         {
         out.assign((size_t)P, 0);

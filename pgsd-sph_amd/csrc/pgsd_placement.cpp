@@ -217,7 +217,10 @@ int deliver_chunk(Impl* s, Queued& q, const Placement& pl, bool skip)
             rc = device_pipeline_commit(s->dev, q.ticket, q.ticket_index, -1, s->write_buffer.data() + at, &err);
             }
         else
+            {
+            s->note_placed(pl.file_offset, pl.size);
             rc = device_pipeline_commit(s->dev, q.ticket, q.ticket_index, pl.file_offset, nullptr, &err);
+            }
         if (rc != PGSD_SUCCESS)
             {
             set_last_error(err);
@@ -237,6 +240,7 @@ int deliver_chunk(Impl* s, Queued& q, const Placement& pl, bool skip)
         return PGSD_SUCCESS;
     // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
     TraceRange tr("pgsd:pwrite_host file_off=%llu bytes=%llu", (unsigned long long)pl.file_offset, pl.size);
+    s->note_placed(pl.file_offset, pl.size);
     int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
     if (e != 0)
         {
@@ -496,6 +500,7 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
             else if (pl.write)
                 {
                 TraceRange tr("pgsd:pwrite_host file_off=%llu bytes=%llu", (unsigned long long)pl.file_offset, pl.size);
+                s->note_placed(pl.file_offset, pl.size);
                 int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
                 if (e != 0)
                     {
@@ -559,6 +564,7 @@ extern "C" int pgsd_write_chunk(struct pgsd_handle* handle, const char* name, en
         else if (pl.write && pl.size > 0)
             {
             // the bytes of the chunk: MPI_File_write_at in the reference (pgsd.c:2229)
+            s->note_placed(pl.file_offset, pl.size);
             int e = writer_pool_pwrite_sync(s->get_pool(), s->fd, data, pl.size, pl.file_offset, s->P > 1);
             if (e != 0)
                 {
@@ -1070,6 +1076,8 @@ extern "C" int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t tic
                 {
                 std::string err;
                 const bool skip = !deliver || pl.size == 0;
+                if (!skip)
+                    s->note_placed(pl.file_offset, pl.size);
                 int drc = device_pipeline_commit(s->dev, e.ticket, i, skip ? -1 : pl.file_offset, nullptr, &err);
                 if (drc != PGSD_SUCCESS && prc == PGSD_SUCCESS)
                     {
@@ -1126,6 +1134,8 @@ extern "C" int pgsd_write_staged_chunks(struct pgsd_handle* handle, uint64_t tic
                 {
                 std::string err;
                 const bool skip = prc != PGSD_SUCCESS || pl.size == 0;
+                if (!skip)
+                    s->note_placed(pl.file_offset, pl.size);
                 int drc = device_pipeline_commit(s->dev, e.ticket, i, skip ? -1 : pl.file_offset, nullptr, &err);
                 if (drc != PGSD_SUCCESS && prc == PGSD_SUCCESS)
                     {

@@ -480,3 +480,29 @@ def test_declared_partition_a_refusal_on_one_rank_reaches_all_at_the_next_sync_a
     rank0_rows = g.read_chunk(1, "particles/position")[:5]            # frame 1: rank 0's rows are there, rank 1's a hole
     np.testing.assert_array_equal(rank0_rows, np.arange(15, dtype=np.float32).reshape(5, 3))
     g.close()
+
+
+def test_index_relocation_costs_one_small_exchange_and_no_barrier(mirror, tmp_gsd):
+    """pgsd_expand_file_index (pgsd.c:965-1091) puts the new block at the file's true end.  The ranks know where that
+    will be from their own placements (the furthest byte each has written or handed to its pipeline): ONE 8-byte
+    allgather, no barrier, no wait for bytes on their way -- a frame sealed asynchronously stays asynchronous when the
+    index moves.  (PGSD_CHECK_EOF=1 keeps the old barrier + fstat beside it and compares: the whole suite passes so.)"""
+    import os
+    f = fl.open(tmp_gsd, "w", application="app", schema="hoomd", schema_version=[1, 4])
+    f.frame_exchange = True
+    per_frame, eight_byte = [], []
+    for i in range(40):                         # 4 entries per frame: the 128-entry block is full after frame 31
+        c0, n0 = f.collective_count, len(mirror.calls)
+        small_frame(f, i)
+        f.write_chunk("particles/position", np.full((5, 3), i, np.float32), offset=np.array([5, 5]), rank=0)
+        f.end_frame()
+        per_frame.append(f.collective_count - c0)
+        eight_byte.append(sum(1 for n in mirror.calls[n0:] if n == 8))
+    extra = 2 if os.environ.get("PGSD_CHECK_EOF") else 1
+    assert sorted(set(per_frame)) == [1, 1 + extra] and per_frame.count(1 + extra) == 1, per_frame
+    k = per_frame.index(1 + extra)
+    assert k == 32 and eight_byte[k] == 1 and sum(eight_byte) == 1, (k, eight_byte)
+    f.close()
+    with fl.open(tmp_gsd, "r") as g:
+        assert g.nframes == 40
+        assert float(g.read_chunk(39, "particles/position")[0, 0]) == 39.0
