@@ -51,8 +51,17 @@ def test_product_golden_device_strided_rows_batched_exchange(name, P, tmp_gsd, t
 @pytest.mark.parametrize("name,P", [c for c in S.golden_cases() if c[1] in (1, 2, 4, 8)])
 def test_product_golden_device_asynchronous_seals(name, P, tmp_gsd, tmp_path):
     """... and with every frame sealed asynchronously (pgsd_end_frame_async: the metadata of the frame committed at
-    once, copies and pwrites running on behind the caller; index relocations fall back to the synchronous seal): the
+    once, copies and pwrites running on behind the caller -- through index relocations too, since round 5): the
     layout does not change by a byte, reads and re-opens in the scenarios see complete frames."""
+    _replay(name, P, tmp_gsd, tmp_path, 1, 1, async_seal=True)
+
+
+@pytest.mark.parametrize("name,P", [c for c in S.golden_cases() if c[0] in ("index_expand", "idxbuf", "benchlike") and c[1] <= 4])
+def test_computed_end_of_file_equals_fstat_on_the_device_path(name, P, tmp_gsd, tmp_path, monkeypatch):
+    """PGSD_CHECK_EOF=1 (tests/test_product_golden.py): every index relocation compares the end of file computed from
+    the ranks' placements -- device chunks count from the moment they are handed to the pipeline -- with fstat's after a
+    drain, and the index mirror with the block on disk; asynchronous seals, batched exchange."""
+    monkeypatch.setenv("PGSD_CHECK_EOF", "1")
     _replay(name, P, tmp_gsd, tmp_path, 1, 1, async_seal=True)
 
 

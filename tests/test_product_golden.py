@@ -155,3 +155,19 @@ def test_ranks_as_threads_match_reference_file(name, P, tmp_gsd):
     with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
         assert f.read() == g.read()
     assert log == S.read_log(golden[:-4] + ".log")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("name,P", [c for c in S.golden_cases() if c[0] in ("index_expand", "idxbuf", "names_reloc", "benchlike", "reopen")])
+def test_computed_end_of_file_equals_fstat_at_every_index_relocation(name, P, mode, tmp_gsd, tmp_path, monkeypatch):
+    """pgsd_expand_file_index places the new block at the file's true end.  The product computes that end from the ranks'
+    placements instead of draining and asking fstat; PGSD_CHECK_EOF=1 does both, compares them -- and the
+    in-memory index mirror with the block on disk -- and fails the flush with PGSD_ERROR_FILE_CORRUPT on a difference.
+    Per-chunk exchange, batched exchange and declared partitions; the file must still be the reference's."""
+    monkeypatch.setenv("PGSD_CHECK_EOF", "1")
+    scn = S.scenario_path(name) if mode == 0 else product.batched_script(S.scenario_path(name), str(tmp_path / "b.scn"), mode)
+    golden = os.path.join(S.GOLDEN, "%s.p%d.gsd" % (name, P))
+    log = product.run_driver(scn, tmp_gsd, P, allow_fail=_fails_on_purpose(golden))
+    assert not any("rc=-5" in ln for ln in log), [ln for ln in log if "rc=" in ln][:5]
+    with open(tmp_gsd, "rb") as f, open(golden, "rb") as g:
+        assert f.read() == g.read()
