@@ -302,9 +302,11 @@ Impl* new_impl(const pgsd_comm* on)
     return s;
     }
 
-// metadata bytes to the file: at once, or -- during an asynchronous seal -- through the pipeline's writer
-// thread, behind the frame's data in the same FIFO (a failure then surfaces like a device chunk's: at the next
-// drain, on every rank at the next flush)
+// metadata bytes to the file: at once, or -- during an asynchronous seal -- through the pipeline's ONE writer
+// thread, in call order and behind what is queued there at that moment: the data of a small (direct-path) frame; the
+// pieces of a frame staged in HBM join the queue as their copies finish, so its index entries may reach the file
+// before its last rows do -- the frame is complete after pgsd_frame_sync(), as pgsd.h says (a failure surfaces like
+// a device chunk's: at the next drain, on every rank at the next flush)
 int meta_pwrite(Impl* s, const void* buf, size_t n, long long offset)
     {
     s->note_placed(offset, n);
