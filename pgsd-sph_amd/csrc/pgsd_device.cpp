@@ -56,6 +56,7 @@ namespace pgsd_amd
         if (e_ != hipSuccess)                                                              \
             {                                                                              \
             fail(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            (void)hipGetLastError(); /* reported; not left for a later launch check to find */ \
             return PGSD_ERROR_DEVICE;                                                      \
             }                                                                              \
         } while (0)

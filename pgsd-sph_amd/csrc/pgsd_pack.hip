@@ -1021,6 +1021,9 @@ int launch_pack(uint32_t n_jobs, const pgsd_pack_job* jobs, uint64_t N, hipStrea
         while (next < n_jobs && done[next])
             next++;
         }
+    // whatever an earlier call of this thread left in the runtime's last-error slot (a failed hipMalloc, the caller's own
+    // calls) is not this launch's: the slot is read again right behind the launches
+    (void)hipGetLastError();
     for (size_t i = 0; i < launches.size(); i++)
         launches[i](i == 0 ? ev_start : nullptr, i + 1 == launches.size() ? ev_stop : nullptr);
     hipError_t e = hipGetLastError();

@@ -181,6 +181,9 @@ int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32
     // one workgroup per 16 KiB of the longest job, at most eight per CU of the part (2048): grid-stride beyond
     uint64_t blocks = (most + 16383) / 16384;
     blocks = std::min<uint64_t>(std::max<uint64_t>(blocks, 1), 2048);
+    // whatever an earlier call of this thread left in the runtime's last-error slot (a failed hipMalloc, the caller's own
+    // calls) is not this launch's: the slot is read again right behind the launches
+    (void)hipGetLastError();
     if (most > 65536)
         {
         args.limit = 65536;
@@ -436,6 +439,9 @@ extern "C" int pgsd_select_rows(const uint8_t* flags, uint64_t N, uint32_t* out_
             sc.host_count_dev = (uint64_t*)alias;
             }
         }
+    // whatever an earlier call of this thread left in the runtime's last-error slot (a failed hipMalloc, the caller's own
+    // calls) is not this launch's: the slot is read again right behind the launches
+    (void)hipGetLastError();
     uint64_t* out_count = (uint64_t*)sc.dev;
     void* workspace = (char*)sc.dev + 8;
     hipStream_t stream = (hipStream_t)stream_;

@@ -558,6 +558,10 @@ static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, 
 
 int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
     {
+    // whatever an earlier call of this thread left in the runtime's last-error slot (a failed hipMalloc, the caller's own
+    // calls) is not this launch's: the slot is read again right behind the launches
+    (void)hipGetLastError();
+
     if (n_jobs == 0 || N == 0)
         return PGSD_SUCCESS;
     std::vector<UnpackJob> all;

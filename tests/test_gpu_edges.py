@@ -538,3 +538,56 @@ def test_preallocated_staging_meets_no_allocation_during_the_run(tmp_path):
     with open(str(tmp_path / "lazy.gsd"), "rb") as a, open(str(tmp_path / "pre.gsd"), "rb") as b:
         assert a.read() == b.read()
     _lib.lib.pgsd_device_release_parked()
+
+
+def test_a_preallocation_the_device_cannot_give_fails_the_call_and_nothing_else(tmp_path):
+    """configure_device(prealloc_mib) beyond the device's memory: the call fails loudly (PGSD_ERROR_DEVICE, the runtime's
+    message), what it had allocated is given back, and the handle works again once it is configured with something the
+    device has."""
+    import pgsd.fl as fl
+    from pgsd import _lib
+    _lib.lib.pgsd_device_release_parked()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    N = 10_000
+    pos = torch.rand((N, 4), device="cuda")
+    path = str(tmp_path / "p.gsd")
+    with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        with pytest.raises(RuntimeError):
+            f.configure_device(prealloc_mib=(free0 >> 20) + 4096)
+        assert "hipMalloc" in _lib.last_error()
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20          # the blocks it got before the one it did not
+        f.configure_device(prealloc_mib=256)
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3)))], offset=np.array([N]))
+        f.end_frame()
+    with fl.open(path, 'r') as f:
+        assert f.read_chunk(0, 'particles/position').tobytes() == pos[:, :3].contiguous().cpu().numpy().tobytes()
+    _lib.lib.pgsd_device_release_parked()
+
+
+def test_a_failed_hip_call_of_the_caller_is_not_mistaken_for_a_failed_launch(tmp_path):
+    """The runtime keeps the last error of a thread until somebody reads it.  A caller whose own hipMalloc has just
+    failed (and who has not asked hipGetLastError) writes a snapshot: the library's launch checks must not find the
+    caller's error and report a kernel launch that never failed."""
+    import pgsd.fl as fl
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    N = 50_000
+    pos = torch.rand((N, 4), device="cuda")
+    flags = (torch.arange(N, device="cuda") % 3 != 0).to(torch.uint8)
+    path = str(tmp_path / "p.gsd")
+    with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        for k in range(2):
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0          # out of memory; the error stays in the slot
+            if k == 0:
+                f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3)))], offset=np.array([N]))
+                f.end_frame()
+            else:
+                idx, n = fl.select_rows(flags)
+                assert n == int(flags.sum().item())
+    with fl.open(path, 'r') as f:
+        assert hip.hipMalloc(ctypes.byref(ctypes.c_void_p()), 1 << 60) != 0
+        got = f.read_chunk_device(0, 'particles/position')              # the unpack launch
+        assert got.cpu().numpy().tobytes() == pos[:, :3].contiguous().cpu().numpy().tobytes()
