@@ -133,6 +133,72 @@ def make_script(seed, P):
     return "\n".join(lines) + "\n"
 
 
+RELOC_TYPES = ["u8", "u16", "u32", "u64", "i8", "i16", "i32", "i64", "f32", "f64"]
+
+
+def make_relocation_script(seed, P):
+    """Relocation-heavy scripts (make_script above rarely fills the 128-entry index): many chunks per frame, many frames,
+    index_entries_to_buffer, flushes in the middle of frames, close + re-open, zero-row ranks -- one to three index
+    relocations per script.  tools/fuzz_relocation.py replays them through the compiled reference as well."""
+    rng = random.Random(seed * 1000003 + P)
+    lines = ["create reloc_%d hoomd 1 4 %s 0" % (seed, rng.choice(["rw", "append"]))]
+    if rng.random() < 0.4:
+        lines.append("maxbuf %d" % rng.choice([16, 64, 4096]))
+    if rng.random() < 0.5:
+        lines.append("idxbuf %d" % rng.choice([1, 3, 40, 200]))
+    n_names = rng.randint(5, 60)
+    shape = {}
+    for k in range(n_names):
+        shape[k] = (rng.choice(RELOC_TYPES), rng.randint(1, 4), rng.random() < 0.6)
+    frames = rng.randint(3, 40)
+    budget = rng.randint(140, 700)                # index entries of the script: one to three relocations
+    per_frame = max(1, min(n_names, budget // frames))
+    for f in range(frames):
+        lines.append("seed %d" % rng.randint(0, 10 ** 6))
+        for k in rng.sample(range(n_names), per_frame):
+            t, M, part = shape[k]
+            if part:
+                dist = ("even:%d" % rng.randint(P, 90)) if rng.random() < 0.8 else \
+                    "list:" + ",".join(str(rng.choice([0, 0, 2, 11, 31])) for _ in range(P))
+                lines.append("chunk r/%d %s %d 1 %s" % (k, t, M, dist))
+            else:
+                lines.append("chunk r/%d %s %d 0 same:%d" % (k, t, M, rng.randint(1, 5)))
+            if rng.random() < 0.02:
+                lines.append("flush")
+        lines.append("end_frame")
+        r = rng.random()
+        if r < 0.06:
+            lines += ["close", "open %s" % rng.choice(["rw", "append"]), "dump"]
+        elif r < 0.12:
+            lines.append("dump")
+    lines += ["dump", "close"]
+    return "\n".join(lines) + "\n"
+
+
+
+@pytest.mark.parametrize("check_eof", ["", "1"])
+@pytest.mark.parametrize("mode", [0, 1, 3])
+@pytest.mark.parametrize("seed,P", [(s, P) for s in range(500, 506) for P in (1, 2, 3) if (s + P) % 2 == 0] + [(506, 5)])
+def test_relocation_heavy_scenarios_equal_the_oracle(seed, P, mode, check_eof, tmp_path, monkeypatch):
+    """One to three index relocations per script, every placement mode, with and without the PGSD_CHECK_EOF cross-check
+    of the computed end of file: file and state trace are the oracle's."""
+    import re
+    if check_eof:
+        monkeypatch.setenv("PGSD_CHECK_EOF", "1")
+    scn = tmp_path / "reloc.scn"
+    scn.write_text(make_relocation_script(seed, P))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "product.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
+    assert any("index_allocated=" in ln and "index_allocated=128 " not in ln for ln in o_log)     # it did relocate
+    s2 = str(scn) if mode == 0 else product.batched_script(str(scn), str(tmp_path / "b.scn"), mode)
+    p_log = product.run_driver(s2, p_path, P)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
+    strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines]
+    assert strip(p_log) == strip(o_log)
+
+
 def have_ref():
     return os.path.exists(REF_DRIVER) and os.path.exists(MPIEXEC)
 

@@ -86,3 +86,24 @@ def test_random_scenarios_from_hbm_equal_the_oracle(seed, P, tmp_path):
         assert a.read() == b.read()
     strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines]
     assert strip(p_log) == strip(o_log)
+
+
+@pytest.mark.parametrize("seed,P", [(s, P) for s in range(500, 500 + max(4, FUZZ_SEEDS // 4)) for P in (1, 2, 3)])
+def test_relocation_heavy_scenarios_from_hbm_with_asynchronous_seals(seed, P, tmp_path):
+    """The relocation-heavy scripts of tests/test_fuzz_parity.py (one to three index relocations each) with every chunk's
+    rows in HBM and EVERY frame sealed asynchronously: since round 5 a seal stays asynchronous when the index moves
+    (the file's true end comes from the ranks' placements), so the new block is placed while earlier frames' copies
+    and writes are still on their way -- file and state trace must be the oracle's."""
+    from test_fuzz_parity import make_relocation_script
+    scn = tmp_path / "reloc.scn"
+    scn.write_text(make_relocation_script(seed, P))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "device.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
+    dscn = product.device_script(str(scn), str(tmp_path / "device.scn"), 2 if seed % 2 else 1, 1, True)
+    p_log = product.run_driver(dscn, p_path, P, driver=product.DEVICE_DRIVER)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        assert a.read() == b.read()
+    strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines
+                           if not ln.startswith("rc ") or not any(c in ln for c in ("cmd=batch", "cmd=device", "cmd=async"))]
+    assert strip(p_log) == strip(o_log)
