@@ -32,7 +32,6 @@ enum
     };
 static const uint64_t DEFAULT_MAXIMUM_WRITE_BUFFER_SIZE = 64ull * 1024 * 1024;
 static const uint64_t DEFAULT_INDEX_ENTRIES_TO_BUFFER = 256ull * 1024;
-static const uint64_t INDEX_COPY_ENTRIES = 256ull * 1024;
 
 static_assert(sizeof(pgsd_header) == 256, "GSD header is 256 bytes on disk");
 static_assert(sizeof(pgsd_index_entry) == 32, "GSD index entry is 32 bytes on disk");
