@@ -591,3 +591,40 @@ def test_a_failed_hip_call_of_the_caller_is_not_mistaken_for_a_failed_launch(tmp
         assert hip.hipMalloc(ctypes.byref(ctypes.c_void_p()), 1 << 60) != 0
         got = f.read_chunk_device(0, 'particles/position')              # the unpack launch
         assert got.cpu().numpy().tobytes() == pos[:, :3].contiguous().cpu().numpy().tobytes()
+
+
+def test_reconfiguring_the_pipeline_in_the_middle_of_a_run(tmp_path):
+    """pgsd_device_configure on a handle with asynchronously sealed frames still on their way: the old pipeline is
+    drained and replaced (other ring geometry, preallocated staging), the frames written before, between and after are
+    the ones a handle that was never reconfigured writes."""
+    import pgsd.fl as fl
+    N = 300_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    arrays = [torch.rand((N, 4), device="cuda", generator=g) for _ in range(8)]
+
+    def frame(f, k, wait):
+        f.write_chunk("configuration/step", np.array([k], dtype=np.uint64), write_all=False)
+        f.write_chunks([('particles/position', fl.DeviceField.from_tensor(arrays[k], columns=(0, 3))),
+                        ('particles/mass', fl.DeviceField.from_tensor(arrays[k], columns=(3, 4)))], offset=np.array([N]))
+        f.end_frame(wait=wait)
+
+    paths = [str(tmp_path / "plain.gsd"), str(tmp_path / "reconfigured.gsd")]
+    for path, reconfigure in zip(paths, (False, True)):
+        with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+            f.frame_exchange = True
+            for k in range(3):
+                frame(f, k, wait=False)
+            if reconfigure:
+                f.configure_device(slab_bytes=1 << 20, n_slabs=3)
+            for k in range(3, 6):
+                frame(f, k, wait=False)
+            if reconfigure:
+                f.configure_device(prealloc_mib=256)
+            for k in range(6, 8):
+                frame(f, k, wait=(k == 7))
+    with open(paths[0], "rb") as a, open(paths[1], "rb") as b:
+        assert a.read() == b.read()
+    with fl.open(paths[1], "r") as f:
+        assert f.nframes == 8
+        for k in (0, 4, 7):
+            assert f.read_chunk(k, "particles/position").tobytes() == arrays[k][:, :3].contiguous().cpu().numpy().tobytes()
