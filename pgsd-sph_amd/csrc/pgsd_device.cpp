@@ -295,6 +295,8 @@ class DevicePipeline
             m_direct_max = (size_t)(atoll(v) > 0 ? atoll(v) : 0) << 10;
         if (const char* v = getenv("PGSD_DIRECT_COALESCE")) // 0: one pwrite per chunk (for A/B measurements)
             m_coalesce = atoi(v) != 0;
+        if (const char* v = getenv("PGSD_STAGING_CAP_MIB")) // how much HBM asynchronously sealed frames may hold before a call waits
+            m_soft_cap = (size_t)(atoll(v) > 0 ? atoll(v) : 6144) << 20;
         ParkedResources adopted;
         bool have_parked = false;
             {
@@ -1170,7 +1172,7 @@ class DevicePipeline
             if (!m_unpack_pending.empty())
                 return PGSD_SUCCESS;
             }
-        const size_t soft_cap = (size_t)6 << 30;
+        const size_t soft_cap = m_soft_cap;
         if (!idle && used < soft_cap)
             return PGSD_SUCCESS;
         if (!idle)
@@ -1698,6 +1700,7 @@ class DevicePipeline
     uint32_t* m_cmp_dev = nullptr;
     uint32_t m_cmp_gen = 0;
     bool m_coalesce = true;                // neighbours in the file leave in one pwritev (write_direct)
+    size_t m_soft_cap = (size_t)6 << 30;   // staging held by frames on their way before stage() waits (PGSD_STAGING_CAP_MIB)
     std::vector<DirectWrite> m_direct;     // committed direct chunks waiting for their pwrite (m_mutex)
     WriterPool* m_pool = nullptr;
     ReadEngine* m_reader = nullptr; // shared reader threads + pinned ring of this device

@@ -1,5 +1,6 @@
 """Edge cases of the device entry points (through pgsd.fl / the C ABI)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -628,3 +629,36 @@ def test_reconfiguring_the_pipeline_in_the_middle_of_a_run(tmp_path):
         assert f.nframes == 8
         for k in (0, 4, 7):
             assert f.read_chunk(k, "particles/position").tobytes() == arrays[k][:, :3].contiguous().cpu().numpy().tobytes()
+
+
+def test_a_small_staging_cap_makes_the_producer_wait_and_changes_nothing_else(tmp_path):
+    """PGSD_STAGING_CAP_MIB: asynchronously sealed frames may hold that much HBM on their way to the file; a producer
+    that runs ahead waits for the backlog when it is reached (a subprocess: the variable is read when the pipeline is
+    made).  The file is the one a synchronous writer produces."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pgsd.fl as fl
+N = 1_000_000
+g = torch.Generator(device="cuda").manual_seed(9)
+pos = torch.rand((N, 4), device="cuda", generator=g)
+for path, wait in ((sys.argv[1], False), (sys.argv[2], True)):
+    with fl.open(path, 'w', application='app', schema='hoomd', schema_version=[1, 4]) as f:
+        f.frame_exchange = True
+        for k in range(40):                       # 16 MB of staging per frame: 640 MB against a cap of 128 MiB
+            pos[:, 0] = float(k)
+            f.write_chunks([('particles/position', fl.DeviceField.from_tensor(pos, columns=(0, 3))),
+                            ('particles/mass', fl.DeviceField.from_tensor(pos, columns=(3, 4)))], offset=np.array([N]))
+            f.end_frame(wait=wait)
+            if not wait:
+                f.wait_packed()
+print("free", torch.cuda.mem_get_info()[0] >> 20)
+""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgsd-sph_amd")
+    a, b = str(tmp_path / "async.gsd"), str(tmp_path / "sync.gsd")
+    p = subprocess.run([sys.executable, "-c", code, a, b], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PGSD_STAGING_CAP_MIB="128", PGSD_NO_PARKING="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
