@@ -286,6 +286,30 @@ def test_select_rows(N, p):
     assert (got[expect.size:] == -1).all()
 
 
+@pytest.mark.parametrize("N,shift", [(10_000_001, 0), (300_007, 3), (4099, 1), (17, 5)])
+def test_select_rows_with_unaligned_flags_on_a_callers_stream(N, shift):
+    """Flags that do not start on a 16-byte boundary (the vector loads fall back to bytes), on a stream of the caller's
+    behind a kernel that produces them; several calls in a row (the scratch space and the pinned count are reused)."""
+    import ctypes
+    from pgsd import _lib
+    rng = np.random.default_rng(N + shift)
+    stream = torch.cuda.Stream()
+    buf = torch.zeros((N + 16,), dtype=torch.uint8, device="cuda")
+    out = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    for keep in (0.5, 0.02, 0.97):
+        flags = (rng.random(N) < keep).astype(np.uint8)
+        host = torch.from_numpy(flags).pin_memory()
+        with torch.cuda.stream(stream):
+            buf[shift:shift + N].copy_(host, non_blocking=True)          # produced on the caller's stream
+            count = ctypes.c_uint64(0)
+            rc = _lib.lib.pgsd_select_rows(buf.data_ptr() + shift, N, out.data_ptr(), ctypes.byref(count), stream.cuda_stream)
+        assert rc == 0, _lib.last_error()
+        expect = np.nonzero(flags)[0].astype(np.int32)
+        assert int(count.value) == expect.size
+        stream.synchronize()
+        assert (out[:expect.size].cpu().numpy() == expect).all()
+
+
 @pytest.mark.parametrize("prefetch", ["default", "1", "0"])
 def test_full_size_pack_matches_independent_gpu_slicing(prefetch, monkeypatch):
     """BASELINE size (10 M particles): compare against torch's own strided copy on the GPU
