@@ -504,7 +504,8 @@ extern "C"
         uint32_t profile;       /* 1 = bracket every pack launch with HIP events */
         uint32_t prealloc_mib;  /* 0: staging blocks (256 MiB of HBM each) and ring slabs are allocated when a frame first
                                    needs them and kept until close.  > 0: this call allocates that much staging (rounded up to
-                                   whole blocks) and the WHOLE ring, so that no snapshot of the run meets an allocation: a
+                                   whole blocks), the WHOLE ring and the comparison's answer words, and has the runtime load the kernels'
+                                   code objects (a millisecond each at first use), so that no snapshot of the run meets any of it: a
                                    hipMalloc / hipHostMalloc in the middle of a run costs 0.03 ... 38 ms depending on the
                                    box's state and stalls streams it has nothing to do with */
         };

@@ -383,6 +383,9 @@ class DevicePipeline
             staged_cap += a.cap;
         if (m_cfg.prealloc_mib)
             {
+            warm_pack_kernels();
+            warm_unpack_kernels();
+            warm_select_kernels();
             int brc = compare_buffers();
             if (brc != PGSD_SUCCESS)
                 return brc;

@@ -655,6 +655,13 @@ PackTuning tuning()
     return g_tuning;
     }
 
+void warm_pack_kernels()
+    {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)pack_generic_kernel);
+    (void)hipGetLastError();
+    }
+
 void reload_pack_tuning()
     {
     std::lock_guard<std::mutex> guard(g_tuning_lock);

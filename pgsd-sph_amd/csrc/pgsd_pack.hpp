@@ -255,6 +255,13 @@ struct CompareArgs
 int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32_t* dflags, uint32_t* hflags,
                    hipStream_t stream, std::string* err);
 
+// The runtime loads a code object when one of its kernels is first used (about a millisecond each: the pack, the unpack and
+// the compare / select kernels are three objects).  A caller who asked for everything up front (prealloc_mib) gets that
+// over with in pgsd_device_configure: one attribute query per object.
+void warm_pack_kernels();
+void warm_unpack_kernels();
+void warm_select_kernels();
+
 // algorithmic traffic of one job: bytes that must be read (needed columns only, plus the
 // gather index) and chunk bytes written
 uint64_t pack_algorithmic_bytes_in(const pgsd_pack_job& j, uint64_t N);

@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void compare_bytes_kernel(const CompareArgs ar
         }
     }
 
+void warm_select_kernels()
+    {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)compare_bytes_kernel);
+    (void)hipGetLastError();
+    }
+
 int launch_compare(uint32_t n_jobs, const CompareJob* jobs, uint32_t gen, uint32_t* dflags, uint32_t* hflags,
                    hipStream_t stream, std::string* err)
     {

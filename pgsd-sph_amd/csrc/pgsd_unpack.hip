@@ -556,6 +556,13 @@ static void launch_unpack_batch(const std::vector<UnpackJob>& jobs, uint64_t N, 
         hipLaunchKernelGGL(unpack_tiles_kernel<false>, dim3((unsigned)blocks), dim3(PACK_THREADS), lds_bytes, stream, args);
     }
 
+void warm_unpack_kernels()
+    {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)fill_cols_kernel);
+    (void)hipGetLastError();
+    }
+
 int launch_unpack(uint32_t n_jobs, const pgsd_unpack_job* jobs, uint64_t N, hipStream_t stream, std::string* err)
     {
     // whatever an earlier call of this thread left in the runtime's last-error slot (a failed hipMalloc, the caller's own
