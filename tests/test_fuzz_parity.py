@@ -199,6 +199,65 @@ def test_relocation_heavy_scenarios_equal_the_oracle(seed, P, mode, check_eof, t
     assert strip(p_log) == strip(o_log)
 
 
+def adversarial_script(kind, P):
+    """Two hand-made call sequences around the index: 300 chunks in ONE frame (the block doubles twice inside one flush),
+    empty frames behind it, a sparse frame, re-open for append; and duplicate names inside frames, empty frames, tiny
+    write and index buffers, mid-frame flushes, two re-opens over 50 frames."""
+    L = ["create adv hoomd 1 4 rw 0"]
+    if kind == "big_frame":
+        L.append("seed 5")
+        for k in range(300):
+            L.append("chunk r/%d %s %d %d %s" % (k, ["f32", "u8", "i64", "f64"][k % 4], 1 + k % 3, 1 if k % 2 else 0,
+                                                 ("even:%d" % (P + k % 40)) if k % 2 else "same:%d" % (1 + k % 4)))
+        L += ["end_frame", "dump", "end_frame", "end_frame", "seed 6"]
+        L += ["chunk r/%d f32 2 1 even:%d" % (k, P + 5) for k in range(0, 300, 7)]
+        L += ["end_frame", "dump", "close", "open append", "dump", "seed 7", "chunk r/3 u8 1 1 even:%d" % (P + 3),
+              "end_frame", "dump", "close"]
+    else:
+        L += ["maxbuf 16", "idxbuf 2"]
+        for f in range(50):
+            L.append("seed %d" % f)
+            if f % 5 == 4:
+                L.append("end_frame")
+                continue
+            for k in (0, 1, 1, 2, 0):
+                L.append("chunk d/%d u32 1 %d %s" % (k, k % 2, ("even:%d" % (P + 2)) if k % 2 else "same:3"))
+            if f % 7 == 0:
+                L.append("flush")
+            L.append("end_frame")
+            if f in (20, 41):
+                L += ["close", "open rw", "dump"]
+        L += ["dump", "close"]
+    return "\n".join(L) + "\n"
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind,P", [(k, P) for k in ("big_frame", "dups_and_empty") for P in (1, 2, 5)])
+def test_adversarial_index_scenarios_equal_the_oracle_and_the_reference(kind, P, mode, tmp_path, monkeypatch):
+    """... through the product in every placement mode with the PGSD_CHECK_EOF cross-check on, against the oracle -- and,
+    where the compiled reference is present (build container), against its file as well."""
+    import re
+    monkeypatch.setenv("PGSD_CHECK_EOF", "1")
+    scn = tmp_path / "adv.scn"
+    scn.write_text(adversarial_script(kind, P))
+    o_path, p_path = str(tmp_path / "oracle.gsd"), str(tmp_path / "product.gsd")
+    o_log = S.run_oracle(str(scn), o_path, P)
+    assert not [ln for ln in o_log if ln.startswith("rc ")], o_log
+    s2 = str(scn) if mode == 0 else product.batched_script(str(scn), str(tmp_path / "b.scn"), mode)
+    p_log = product.run_driver(s2, p_path, P)
+    with open(o_path, "rb") as a, open(p_path, "rb") as b:
+        want = a.read()
+        assert want == b.read()
+    strip = lambda lines: [re.sub(r"line=\d+ ", "", ln) for ln in lines]
+    assert strip(p_log) == strip(o_log)
+    if mode == 0 and have_ref():
+        r_path = str(tmp_path / "ref.gsd")
+        out = subprocess.run([MPIEXEC, "-n", str(P), REF_DRIVER, str(scn), r_path], capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()[-500:]
+        with open(r_path, "rb") as r:
+            assert r.read() == want
+
+
 def have_ref():
     return os.path.exists(REF_DRIVER) and os.path.exists(MPIEXEC)
 
