@@ -18,11 +18,11 @@ def _build_if_missing():
     from product import locked_make
     lib = os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "libpgsd_amd.so")
     drv = os.path.join(ROOT, "tests", "build", "scenario_driver")
-    ext = glob.glob(os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "_fl.*.so"))      # the Cython file layer (pgsd.fl)
     # always `make` (a no-op when up to date), under the session's lock: with pytest-xdist every worker passes here
     # before it runs anything, so a library or driver is never relinked while another worker executes it
     locked_make(["-C", os.path.join(ROOT, "pgsd-sph_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     locked_make(["-C", os.path.join(ROOT, "tests"), "-j8"], stdout=subprocess.DEVNULL)
+    ext = glob.glob(os.path.join(ROOT, "pgsd-sph_amd", "pgsd", "_fl.*.so"))      # the Cython file layer (pgsd.fl)
     if not (os.path.exists(lib) and os.path.exists(drv) and ext):
         raise RuntimeError("make did not produce libpgsd_amd.so / scenario_driver / the pgsd.fl extension")
     if not os.path.exists(os.path.join(ROOT, "oracle", "libpgsd_oracle.so")):
