@@ -7,8 +7,9 @@
 //   copy stream   waits for the pack event, then streams the staged bytes piece by piece
 //                 into a ring of pinned host slabs with hipMemcpyAsync, so the copy of piece
 //                 k+1 overlaps the file write of piece k and the pack of the next chunk.
-//                 On the MI355X boxes of this project the runtime executes these copies as
-//                 SHADER BLITS, not on an SDMA engine: they appear in the kernel trace as
+//                 With the HIP runtime PyTorch ships (bench.py, pgsd.hoomd under torch) these copies run as
+//                 SHADER BLITS, not on an SDMA engine (a HIP-only process on ROCm 7.2's own runtime shows no
+//                 copy kernels: examples/dump_writer.hip): they appear in the kernel trace as
 //                 __amd_rocclr_copyBuffer (240 dispatches of ~256 us for 12 frames of 10 M
 //                 particles, profiles/r03_kernel_stats_10M.csv) and share the CUs with whatever
 //                 the simulation runs.  They are PCIe-bound (50-55 GB/s) and need few CUs:
